@@ -1,0 +1,92 @@
+"""ctypes binding of libmslam_hip.so (C ABI declared in include/mslam_hip.h).
+
+This is the only place that touches the shared library.  There is deliberately NO fallback: if the
+library is missing, or a tensor is not resident on a HIP device, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmslam_hip.so")
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_c_vp = ctypes.c_void_p
+_c_i64 = ctypes.c_int64
+_c_double = ctypes.c_double
+_c_size = ctypes.c_size_t
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "mslam_abi_version": [],
+    "mslam_device_check": [],
+    "mslam_iter_proj": [_c_vp] * 5 + [_c_int] * 5 + [_c_float, _c_float, _c_vp],
+    "mslam_refine_matches": [_c_vp] * 4 + [_c_int] * 7 + [_c_vp],
+    "mslam_prep_iter_proj": [_c_vp] * 6 + [_c_int] * 3 + [_c_vp],
+    "mslam_match_occlusion": [_c_vp] * 5 + [_c_int] * 3 + [_c_float, _c_vp],
+    "mslam_pixel_to_lin": [_c_vp] * 2 + [_c_int] * 3 + [_c_vp],
+}
+_RESTYPES = {"mslam_last_error": ctypes.c_char_p}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every symbol include/mslam_hip.h declares (used by the CPU-side ABI test)."""
+    return sorted(list(_SIGNATURES) + list(_RESTYPES))
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        handle.mslam_last_error.argtypes = []
+        handle.mslam_last_error.restype = ctypes.c_char_p
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().mslam_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (None -> NULL).  Raises for host tensors: no CPU path exists."""
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise RuntimeError(
+            "libmslam_hip.so operates on HIP device tensors only; got a tensor on "
+            f"{t.device}. There is no CPU fallback."
+        )
+    return t.data_ptr()
+
+
+def require_contiguous(**tensors) -> None:
+    """Mirror of CHECK_CONTIGUOUS (mast3r_slam/backend/include/gn.h:5): RuntimeError by name."""
+    for name, t in tensors.items():
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be contiguous")
+
+
+def require_dtype(t, dtype, name: str) -> None:
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {t.dtype}")
