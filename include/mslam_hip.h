@@ -74,6 +74,80 @@ int mslam_match_occlusion(const float* X11, const float* X21, const float* p, in
 /* idx = u + w*v  (mast3r_slam/matching.py:13-15). p1 i64[b,n,2] -> idx i64[b,n]. */
 int mslam_pixel_to_lin(const int64_t* p1, int64_t* idx, int b, int n, int w, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Gauss-Newton backend  (pybind gauss_newton_{rays,calib,points}, gn.cpp:3-82;
+ *                        host loops gn_kernels.cu:725-811, 1140-1228, 1546-1638)
+ *
+ * Shapes: Twc f32[P,8] ([t,q(xyzw),s], UPDATED IN PLACE for rows >= 1), Xs f32[P,HW,3],
+ * Cs f32[P,HW,1], ii/jj i64[E] (global keyframe ids; the callee maps them to rows with
+ * unique+searchsorted and pins the first unique id, gn_kernels.cu:161-170,1157),
+ * idx_ii2jj i64[E,HW], valid_match u8[E,HW,1], Q f32[E,HW,1], K f32[3,3] (device), dx f32[P-1,7].
+ * `workspace` is a caller-owned device buffer of >= mslam_gn_workspace_bytes(P,E,HW) bytes.
+ * The whole GN loop is enqueued on `stream` with NO host synchronisation: convergence
+ * (||dx|| < delta_thresh, gn_kernels.cu:1219-1222) is a device-side flag that turns the remaining
+ * iterations' kernels into no-ops.  LLT failure => dx = 0 (gn_kernels.cu:147-150).
+ * ------------------------------------------------------------------------------------------ */
+size_t mslam_gn_workspace_bytes(int num_poses, int num_edges, int num_points);
+
+/* Replaces gauss_newton_rays (gn.cpp:28-52; ray_align_kernel gn_kernels.cu:813-1138). */
+int mslam_gauss_newton_rays(float* Twc, const float* Xs, const float* Cs, const int64_t* ii,
+                            const int64_t* jj, const int64_t* idx_ii2jj, const uint8_t* valid_match,
+                            const float* Q, int num_poses, int num_points, int num_edges,
+                            float sigma_ray, float sigma_dist, float C_thresh, float Q_thresh,
+                            int max_iter, float delta_thresh, float* dx, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* Replaces gauss_newton_calib (gn.cpp:54-82; calib_proj_kernel gn_kernels.cu:1231-1543). */
+int mslam_gauss_newton_calib(float* Twc, const float* Xs, const float* Cs, const float* K,
+                             const int64_t* ii, const int64_t* jj, const int64_t* idx_ii2jj,
+                             const uint8_t* valid_match, const float* Q, int num_poses, int num_points,
+                             int num_edges, int height, int width, int pixel_border, float z_eps,
+                             float sigma_pixel, float sigma_depth, float C_thresh, float Q_thresh,
+                             int max_iter, float delta_thresh, float* dx, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* Replaces gauss_newton_points (gn.cpp:3-26; point_align_kernel gn_kernels.cu:455-723). */
+int mslam_gauss_newton_points(float* Twc, const float* Xs, const float* Cs, const int64_t* ii,
+                              const int64_t* jj, const int64_t* idx_ii2jj, const uint8_t* valid_match,
+                              const float* Q, int num_poses, int num_points, int num_edges,
+                              float sigma_point, float C_thresh, float Q_thresh, int max_iter,
+                              float delta_thresh, float* dx, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* The same loop opened up for the multi-GPU factor graph (global_opt.py:123-223): every rank calls
+ * begin() with the FULL edge list, accumulate() for ITS edge range (per-edge inputs are local arrays
+ * of edge_count rows; Hs f32[4,E,7,7] / gs f32[2,E,7] are the global, reference-layout buffers
+ * [ii,ij,ji,jj] / [i,j], gn_kernels.cu:1120-1133), all-reduces Hs and gs (RCCL sum; slots of other
+ * ranks' edges are zero), then solve_retract(), which is bit-identical on every rank.
+ * kind: 0 rays (sigma_a=ray, sigma_b=dist), 1 calib (pixel, depth), 2 points (point, -). */
+int mslam_gn_begin(const int64_t* ii, const int64_t* jj, int num_poses, int num_edges, int num_points,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int mslam_gn_accumulate(int kind, const float* Twc, const float* Xs, const float* Cs, const float* K,
+                        const int64_t* idx_ii2jj, const uint8_t* valid_match, const float* Q,
+                        int num_poses, int num_points, int num_edges, int edge_begin, int edge_count,
+                        float sigma_a, float sigma_b, float C_thresh, float Q_thresh, int height,
+                        int width, int pixel_border, float z_eps, float* Hs, float* gs, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int mslam_gn_solve_retract(const float* Hs, const float* gs, int num_poses, int num_edges,
+                           int num_points, float* Twc, float* dx, float delta_thresh, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* status4 (device i32[4]) <- {done, iterations run, chol_fail, bits of last ||dx|| (f32)}. */
+int mslam_gn_status(int* status4, int num_poses, int num_edges, int num_points, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sim3 group ops (lietorch.Sim3 surface used by the hot path: act / inv / mul / exp / retr;
+ * call sites tracker.py:150,232,247,264, geometry.py:45-52, global_manager.py:88-105;
+ * maths restated in gn_kernels.cu:177-413).  Pose layout f32[n,8] = [t, q(xyzw), s]; xi f32[n,7]
+ * = [tau, phi, sigma].  Forward only.
+ * ------------------------------------------------------------------------------------------ */
+/* Y[i] = T[pose(i)] . X[i]; pose(i) = i / pts_per_pose, or 0 when broadcast_pose. */
+int mslam_sim3_act(const float* T, const float* X, float* Y, int num_poses, long long pts_per_pose,
+                   int broadcast_pose, void* stream);
+/* op 0: out = A^-1 ; 1: out = A*B ; 2: out = exp(A as xi) ; 3: out = exp(A as xi) * B (retr). */
+int mslam_sim3_op(int op, const float* A, const float* B, float* out, int n, int bcast_a, int bcast_b,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

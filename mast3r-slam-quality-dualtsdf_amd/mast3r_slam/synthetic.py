@@ -111,3 +111,67 @@ def render_rgb(T_wc, h=384, w=512, K=None):
     g = np.sin(2.3 * Pw[..., 1] + 2.9 * Pw[..., 2])
     b = np.sin(4.1 * Pw[..., 2] + 1.3 * Pw[..., 0])
     return np.stack((r, g, b), 0).astype(np.float32)
+
+
+def project(K, X):
+    z = X[..., 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = K[0, 0] * X[..., 0] / z + K[0, 2]
+        v = K[1, 1] * X[..., 1] / z + K[1, 2]
+    return u, v, z
+
+
+def make_graph(n_kf=4, h=24, w=32, stride=8, extra_edges=2, seed=0, pose_noise=0.01, point_noise=0.0,
+               n_frames=1000):
+    """A small factor graph in the reference's layout (global_opt.py:106-121): keyframes every
+    `stride` frames, edges (k-1,k) plus `extra_edges` random earlier ones, BOTH directions
+    (prep_two_way_edges).  Correspondences are geometric nearest pixels with an occlusion test.
+    Returns a dict of numpy arrays: Twc_gt/Twc (P,8) f32, Xs (P,HW,3), Cs (P,HW,1), K (3,3),
+    ii/jj (E) i64 global ids, idx_ii2jj (E,HW) i64, valid_match (E,HW,1) bool, Q (E,HW,1) f32."""
+    rng = np.random.default_rng(seed)
+    K = intrinsics(h, w)
+    ids = np.arange(n_kf) * 3 + 5  # non-contiguous global keyframe ids on purpose
+    T_gt = np.stack([camera_pose(k * stride, n_frames) for k in range(n_kf)])
+    Xs = np.stack([render_pointmap(T, h, w, K).reshape(-1, 3) for T in T_gt])
+    Xs = Xs + rng.normal(0, point_noise, Xs.shape) if point_noise > 0 else Xs
+    Cs = rng.uniform(1.0, 3.0, (n_kf, h * w, 1))
+    und = [(k - 1, k) for k in range(1, n_kf)]
+    for k in range(2, n_kf):
+        for m in rng.choice(k - 1, size=min(extra_edges, k - 1), replace=False):
+            und.append((int(m), k))
+    ii = np.array([a for a, b in und] + [b for a, b in und], np.int64)
+    jj = np.array([b for a, b in und] + [a for a, b in und], np.int64)
+    E = len(ii)
+    idx = np.zeros((E, h * w), np.int64)
+    valid = np.zeros((E, h * w, 1), bool)
+    for e in range(E):
+        i, j = ii[e], jj[e]
+        Pw = sim3_act(T_gt[j], Xs[j])
+        Xi_pred = sim3_act(sim3_inv(T_gt[i]), Pw)
+        u, v, z = project(K, Xi_pred)
+        ui, vi = np.rint(u).astype(np.int64), np.rint(v).astype(np.int64)
+        inside = (z > 0.05) & (ui >= 0) & (ui < w) & (vi >= 0) & (vi < h)
+        lin = np.where(inside, vi * w + ui, 0)
+        occl = np.linalg.norm(Xs[i][lin] - Xi_pred, axis=-1) < 0.1
+        idx[e] = lin
+        valid[e, :, 0] = inside & occl
+    Q = rng.uniform(1.0, 4.0, (E, h * w, 1))
+    # noisy initial poses (first pose exact: it is the pinned one)
+    T = T_gt.copy()
+    for k in range(1, n_kf):
+        xi = rng.normal(0, pose_noise, 7)
+        dq = quat_from_rotvec(xi[3:6])
+        ds = np.exp(xi[6] * 0.5)
+        q = T[k, 3:7]
+        # left-multiply a small Sim3
+        qn = np.array([
+            dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1],
+            dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0],
+            dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3],
+            dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2]])
+        T[k, :3] = ds * quat_rotate(dq, T[k, :3][None])[0] + xi[:3]
+        T[k, 3:7] = qn
+        T[k, 7] = ds * T[k, 7]
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    return dict(Twc_gt=f32(T_gt), Twc=f32(T), Xs=f32(Xs), Cs=f32(Cs), K=f32(K), ii=ids[ii], jj=ids[jj],
+                idx_ii2jj=idx, valid_match=valid, Q=f32(Q), h=h, w=w)

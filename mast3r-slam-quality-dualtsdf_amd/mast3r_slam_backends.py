@@ -48,3 +48,113 @@ def refine_matches(D11, D21, p1, radius, dilation_max):
     )
     _m.check(rc, "refine_matches")
     return [p1_new]
+
+
+# ------------------------------------------------------------------------------------------------
+# Gauss-Newton backend
+# ------------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (the reference allocates Hs/gs/dx per call with
+    torch::zeros, gn_kernels.cu:1173-1174; a cached buffer keeps the call graph-capturable)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _gn_common_checks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q):
+    _m.require_contiguous(Twc=Twc, Xs=Xs, Cs=Cs, ii=ii, jj=jj, idx_ii2jj=idx_ii2jj, valid_match=valid_match, Q=Q)
+    for name, t in (("Twc", Twc), ("Xs", Xs), ("Cs", Cs), ("Q", Q)):
+        _m.require_dtype(t, torch.float32, name)
+    for name, t in (("ii", ii), ("jj", jj), ("idx_ii2jj", idx_ii2jj)):
+        _m.require_dtype(t, torch.int64, name)
+    _m.require_dtype(valid_match, torch.bool, "valid_match")
+    P, HW = Xs.shape[0], Xs.shape[1]
+    E = ii.shape[0]
+    if Twc.shape[0] != P:
+        raise RuntimeError(f"Twc has {Twc.shape[0]} poses but Xs has {P}")
+    return P, HW, E
+
+
+def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray, sigma_dist, C_thresh,
+                      Q_thresh, max_iter, delta_thresh):
+    """gn.cpp:28-52 / gn_kernels.cu:1140-1228.  Mutates Twc in place (rows >= 1); returns [dx]."""
+    P, HW, E = _gn_common_checks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q)
+    dx = torch.zeros((max(P - 1, 0), 7), dtype=torch.float32, device=Twc.device)
+    nbytes = _m.lib().mslam_gn_workspace_bytes(P, E, HW)
+    ws = _workspace(nbytes, Twc.device)
+    rc = _m.lib().mslam_gauss_newton_rays(
+        _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(ii), _m.ptr(jj), _m.ptr(idx_ii2jj), _m.ptr(valid_match),
+        _m.ptr(Q), P, HW, E, float(sigma_ray), float(sigma_dist), float(C_thresh), float(Q_thresh),
+        int(max_iter), float(delta_thresh), _m.ptr(dx), _m.ptr(ws), ws.numel(), _m.stream_ptr(),
+    )
+    _m.check(rc, "gauss_newton_rays")
+    return [dx]
+
+
+def gauss_newton_calib(Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, height, width, pixel_border, z_eps,
+                       sigma_pixel, sigma_depth, C_thresh, Q_thresh, max_iter, delta_thresh):
+    """gn.cpp:54-82 / gn_kernels.cu:1546-1638."""
+    P, HW, E = _gn_common_checks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q)
+    _m.require_contiguous(K=K)
+    _m.require_dtype(K, torch.float32, "K")
+    dx = torch.zeros((max(P - 1, 0), 7), dtype=torch.float32, device=Twc.device)
+    nbytes = _m.lib().mslam_gn_workspace_bytes(P, E, HW)
+    ws = _workspace(nbytes, Twc.device)
+    rc = _m.lib().mslam_gauss_newton_calib(
+        _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(K), _m.ptr(ii), _m.ptr(jj), _m.ptr(idx_ii2jj),
+        _m.ptr(valid_match), _m.ptr(Q), P, HW, E, int(height), int(width), int(pixel_border), float(z_eps),
+        float(sigma_pixel), float(sigma_depth), float(C_thresh), float(Q_thresh), int(max_iter),
+        float(delta_thresh), _m.ptr(dx), _m.ptr(ws), ws.numel(), _m.stream_ptr(),
+    )
+    _m.check(rc, "gauss_newton_calib")
+    return [dx]
+
+
+def gauss_newton_points(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_point, C_thresh, Q_thresh,
+                        max_iter, delta_thresh):
+    """gn.cpp:3-26 / gn_kernels.cu:725-811 (exported by the reference, never called from its Python)."""
+    P, HW, E = _gn_common_checks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q)
+    dx = torch.zeros((max(P - 1, 0), 7), dtype=torch.float32, device=Twc.device)
+    nbytes = _m.lib().mslam_gn_workspace_bytes(P, E, HW)
+    ws = _workspace(nbytes, Twc.device)
+    rc = _m.lib().mslam_gauss_newton_points(
+        _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(ii), _m.ptr(jj), _m.ptr(idx_ii2jj), _m.ptr(valid_match),
+        _m.ptr(Q), P, HW, E, float(sigma_point), float(C_thresh), float(Q_thresh), int(max_iter),
+        float(delta_thresh), _m.ptr(dx), _m.ptr(ws), ws.numel(), _m.stream_ptr(),
+    )
+    _m.check(rc, "gauss_newton_points")
+    return [dx]
+
+
+# --- opened-up loop (multi-GPU factor graph; see include/mslam_hip.h) ---------------------------
+_KIND = {"rays": 0, "calib": 1, "points": 2}
+
+
+def gn_blocks(kind, Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, sigma_a, sigma_b, C_thresh, Q_thresh,
+              height=0, width=0, pixel_border=0, z_eps=0.0, edge_begin=0, edge_count=None, Hs=None, gs=None):
+    """One accumulation pass: returns (Hs f32[4,E,7,7], gs f32[2,E,7]) in the reference's block
+    layout (gn_kernels.cu:1120-1133) for edges [edge_begin, edge_begin+edge_count)."""
+    P, HW = Xs.shape[0], Xs.shape[1]
+    E = ii.shape[0]
+    edge_count = E - edge_begin if edge_count is None else edge_count
+    dev = Twc.device
+    if Hs is None:
+        Hs = torch.zeros((4, E, 7, 7), dtype=torch.float32, device=dev)
+        gs = torch.zeros((2, E, 7), dtype=torch.float32, device=dev)
+    ws = _workspace(_m.lib().mslam_gn_workspace_bytes(P, E, HW), dev)
+    L = _m.lib()
+    _m.check(L.mslam_gn_begin(_m.ptr(ii), _m.ptr(jj), P, E, HW, _m.ptr(ws), ws.numel(), _m.stream_ptr()), "gn_begin")
+    rc = L.mslam_gn_accumulate(
+        _KIND[kind], _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(K), _m.ptr(idx_ii2jj), _m.ptr(valid_match),
+        _m.ptr(Q), P, HW, E, int(edge_begin), int(edge_count), float(sigma_a), float(sigma_b), float(C_thresh),
+        float(Q_thresh), int(height), int(width), int(pixel_border), float(z_eps), _m.ptr(Hs), _m.ptr(gs),
+        _m.ptr(ws), ws.numel(), _m.stream_ptr(),
+    )
+    _m.check(rc, "gn_accumulate")
+    return Hs, gs

@@ -80,3 +80,111 @@ def refine_matches(D11, D21, p1, radius, dilation_max, fused_fma=False):
         ctypes.c_int(radius), ctypes.c_int(dilation_max), ctypes.c_int(int(fused_fma)),
     )
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Gauss-Newton backend (oracle/gn_ref.c)
+# ----------------------------------------------------------------------------------------------
+KIND = {"rays": 0, "calib": 1, "points": 2}
+
+
+def _ci(x):
+    return ctypes.c_int(int(x))
+
+
+def _cf(x):
+    return ctypes.c_float(float(x))
+
+
+def edge_rows(ii, jj, num_fix=1):
+    """get_unique_kf_idx + create_inds (gn_kernels.cu:161-170): (unique, ii_edge, jj_edge, ii_opt, jj_opt)."""
+    ii = np.asarray(ii, np.int64)
+    jj = np.asarray(jj, np.int64)
+    uniq = np.unique(np.concatenate((ii, jj)))
+    ie = np.searchsorted(uniq, ii).astype(np.int64)
+    je = np.searchsorted(uniq, jj).astype(np.int64)
+    return uniq, ie, je, ie - num_fix, je - num_fix
+
+
+def gn_edges(kind, Twc, Xs, Cs, K, ii_edge, jj_edge, idx_ii2jj, valid_match, Q, sigma_a, sigma_b, C_thresh,
+             Q_thresh, height=0, width=1, pixel_border=0, z_eps=0.0):
+    """One launch of the reference's edge kernel: returns Hs (4,E,7,7), gs (2,E,7)."""
+    Twc = _c(Twc, np.float32); Xs = _c(Xs, np.float32); Cs = _c(Cs, np.float32)
+    ie = _c(ii_edge, np.int64); je = _c(jj_edge, np.int64)
+    idx = _c(idx_ii2jj, np.int64); vm = _c(valid_match, np.uint8); Qc = _c(Q, np.float32)
+    E, HW = idx.shape[0], Xs.shape[1]
+    Hs = np.zeros((4, E, 7, 7), np.float32)
+    gs = np.zeros((2, E, 7), np.float32)
+    Kc = _c(K, np.float32) if K is not None else None
+    lib().oracle_gn_edges(
+        _ci(KIND[kind]), _p(Twc), _p(Xs), _p(Cs), _p(Kc) if Kc is not None else None, _p(ie), _p(je), _p(idx),
+        _p(vm), _p(Qc), _ci(HW), _ci(E), _cf(sigma_a), _cf(sigma_b), _cf(C_thresh), _cf(Q_thresh), _ci(height),
+        _ci(width), _ci(pixel_border), _cf(z_eps), _p(Hs), _p(gs))
+    return Hs, gs
+
+
+def gn_solve(Hs, gs, ii_opt, jj_opt, N):
+    """SparseBlock assemble + LL^T solve (gn_kernels.cu:57-159): returns (dx (N,7) f32, failed)."""
+    Hs = _c(Hs, np.float32); gs = _c(gs, np.float32)
+    io = _c(ii_opt, np.int64); jo = _c(jj_opt, np.int64)
+    dx = np.zeros((N, 7), np.float32)
+    lib().oracle_gn_solve.restype = ctypes.c_int
+    fail = lib().oracle_gn_solve(_p(Hs), _p(gs), _p(io), _p(jo), _ci(io.shape[0]), _ci(N), _p(dx))
+    return dx, bool(fail)
+
+
+def gauss_newton(kind, Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, sigma_a, sigma_b, C_thresh, Q_thresh,
+                 max_iter, delta_thresh, height=0, width=1, pixel_border=0, z_eps=0.0):
+    """Full host loop (gn_kernels.cu:1140-1228 etc.).  Returns (Twc_new, dx, iterations)."""
+    Twc = np.array(Twc, np.float32, copy=True, order="C")
+    Xs = _c(Xs, np.float32); Cs = _c(Cs, np.float32)
+    ii = _c(ii, np.int64); jj = _c(jj, np.int64)
+    idx = _c(idx_ii2jj, np.int64); vm = _c(valid_match, np.uint8); Qc = _c(Q, np.float32)
+    P, HW = Xs.shape[0], Xs.shape[1]
+    E = ii.shape[0]
+    dx = np.zeros((P - 1, 7), np.float32)
+    Kc = _c(K, np.float32) if K is not None else None
+    lib().oracle_gauss_newton.restype = ctypes.c_int
+    iters = lib().oracle_gauss_newton(
+        _ci(KIND[kind]), _p(Twc), _p(Xs), _p(Cs), _p(Kc) if Kc is not None else None, _p(ii), _p(jj), _p(idx),
+        _p(vm), _p(Qc), _ci(P), _ci(HW), _ci(E), _cf(sigma_a), _cf(sigma_b), _cf(C_thresh), _cf(Q_thresh),
+        _ci(height), _ci(width), _ci(pixel_border), _cf(z_eps), _ci(max_iter), _cf(delta_thresh), _p(dx))
+    return Twc, dx, iters
+
+
+def sim3_exp(xi):
+    xi = _c(xi, np.float32).reshape(-1, 7)
+    out = np.zeros((xi.shape[0], 8), np.float32)
+    for k in range(xi.shape[0]):
+        lib().oracle_sim3_exp(_p(xi[k]), _p(out[k]))
+    return out
+
+
+def sim3_retr(xi, T):
+    xi = _c(xi, np.float32).reshape(-1, 7); T = _c(T, np.float32).reshape(-1, 8)
+    out = np.zeros_like(T)
+    for k in range(T.shape[0]):
+        lib().oracle_sim3_retr(_p(xi[k]), _p(T[k]), _p(out[k]))
+    return out
+
+
+def sim3_rel(Ti, Tj):
+    Ti = _c(Ti, np.float32).reshape(-1, 8); Tj = _c(Tj, np.float32).reshape(-1, 8)
+    out = np.zeros_like(Ti)
+    for k in range(Ti.shape[0]):
+        lib().oracle_sim3_rel(_p(Ti[k]), _p(Tj[k]), _p(out[k]))
+    return out
+
+
+def sim3_act(T, X):
+    T = _c(T, np.float32).reshape(8); X = _c(X, np.float32).reshape(-1, 3)
+    Y = np.zeros_like(X)
+    lib().oracle_sim3_act(_p(T), _p(X), _p(Y), _ci(X.shape[0]))
+    return Y
+
+
+def sim3_adj_inv(T, x7):
+    T = _c(T, np.float32).reshape(8); x7 = _c(x7, np.float32).reshape(7)
+    y = np.zeros(7, np.float32)
+    lib().oracle_sim3_adj_inv(_p(T), _p(x7), _p(y))
+    return y

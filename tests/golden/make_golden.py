@@ -55,6 +55,84 @@ def section_prep():
 
 SECTIONS = {"prep": section_prep}
 
+
+
+def section_tracker():
+    """Normal equations of ONE relative-pose GN step built with the reference's own pure-torch
+    geometry (mast3r_slam/geometry.py: act_Sim3, point_to_ray_dist, project_calib, backproject;
+    mast3r_slam/nonlinear_optimizer.py: huber) exactly as tracker.py:208-318 composes them, in
+    float64.  lietorch is not installed: geometry.py only needs the module object for a type
+    annotation and a duck-typed pose with .act(), supplied here."""
+    import types
+
+    from mast3r_slam import synthetic
+
+    sys.modules.setdefault("lietorch", types.SimpleNamespace(Sim3=object))
+    geom = load_by_path("ref_geometry", f"{REF}/mast3r_slam/geometry.py")
+    nlo = load_by_path("ref_nlo", f"{REF}/mast3r_slam/nonlinear_optimizer.py")
+
+    class Pose:  # duck-typed lietorch.Sim3: X -> s R X + t
+        def __init__(self, T):
+            self.T = np.asarray(T, np.float64)
+
+        def act(self, X):
+            return torch.from_numpy(synthetic.sim3_act(self.T, X.numpy()))
+
+    g = synthetic.make_graph(n_kf=2, h=12, w=16, seed=0, pose_noise=0.02, extra_edges=0)
+    sys.path.insert(0, ROOT)
+    import oracle
+
+    rng = np.random.default_rng(0)
+    Tj = oracle.sim3_exp(rng.normal(0, 0.05, 7))[0]
+    Twc = np.stack([np.array([0, 0, 0, 0, 0, 0, 1, 1], np.float32), Tj])
+    idx = torch.from_numpy(g["idx_ii2jj"][0])
+    valid = torch.from_numpy(g["valid_match"][0]).double()
+    Q = torch.from_numpy(g["Q"][0]).double()
+    Cs = torch.from_numpy(g["Cs"]).double()
+    K = torch.from_numpy(g["K"]).double()
+    h, w = g["h"], g["w"]
+    out = dict(Twc=Twc)
+    for kind in ("rays", "calib"):
+        Xs = torch.from_numpy(g["Xs"]).double()
+        if kind == "calib":  # global_opt.py:180-182
+            Xs = geom.constrain_points_to_ray((h, w), Xs.view(2, h, w, 3), K).view(2, h * w, 3)
+            out["Xs_calib"] = Xs.numpy().astype(np.float32)
+        Xi = Xs[0][idx]           # measurement in frame i (gathered)   gn_kernels.cu:916
+        Xj = Xs[1]                # points of j
+        valid_all = valid * (Q > 1.5) * (Cs[0][idx] > 0.0) * (Cs[1] > 0.0)
+        P, dP_dT = geom.act_Sim3(Pose(Tj.astype(np.float64)), Xj, jacobian=True)
+        if kind == "rays":
+            rd_i = geom.point_to_ray_dist(Xi, jacobian=False)
+            rd_j, drd_dP = geom.point_to_ray_dist(P, jacobian=True)
+            r = rd_i - rd_j                                   # tracker.py:241 (z - h(x))
+            J = -drd_dP @ dP_dT                               # tracker.py:243
+            s_a, s_b, na = 0.003, 10.0, 3
+        else:
+            pz, dpz_dP, valid_proj = geom.project_calib(P, K, (h, w), jacobian=True, border=-10, z_eps=1e-6)
+            uv = geom.get_pixel_coords(1, (h, w), device="cpu", dtype=torch.float64).view(-1, 2)[idx]
+            valid_i = Xi[:, 2:3] > 1e-6
+            meas = torch.cat((uv, torch.log(Xi[:, 2:3])), -1)
+            meas[~valid_i.repeat(1, 3)] = 0.0                 # tracker.py:199-203
+            r = meas - pz                                     # tracker.py:300
+            J = -dpz_dP @ dP_dT
+            valid_all = valid_all * valid_proj * valid_i
+            s_a, s_b, na = 1.0, 10.0, 2
+        sqrt_info = torch.cat(((1 / s_a * valid_all * torch.sqrt(Q)).repeat(1, na),
+                               1 / s_b * valid_all * torch.sqrt(Q)), 1)   # tracker.py:227-229
+        whitened = sqrt_info * r
+        robust = sqrt_info * torch.sqrt(nlo.huber(whitened, k=1.345))      # tracker.py:209-212
+        A = (robust[..., None] * J).view(-1, 7)
+        b = (robust * r).view(-1, 1)
+        out[f"H_{kind}"] = (A.T @ A).numpy()
+        # kernel convention: err = -r, raw rows = -J  =>  gs_j = sum w err x = A^T b
+        out[f"g_{kind}"] = (A.T @ b).numpy()[:, 0]
+    np.savez_compressed(os.path.join(HERE, "tracker_formulae.npz"), **out, **meta())
+    print("tracker_formulae.npz", {k: v.shape for k, v in out.items()})
+
+
+SECTIONS["tracker"] = section_tracker
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s in todo:
