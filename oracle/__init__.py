@@ -188,3 +188,63 @@ def sim3_adj_inv(T, x7):
     y = np.zeros(7, np.float32)
     lib().oracle_sim3_adj_inv(_p(T), _p(x7), _p(y))
     return y
+
+
+# ----------------------------------------------------------------------------------------------
+# global sparse TSDF (oracle/tsdf_ref.c)
+# ----------------------------------------------------------------------------------------------
+class TSDFVolume:
+    """Restatement of mast3r_slam/tsdf/global_volume.py:15-140 (same constructor / method names)."""
+
+    def __init__(self, voxel_size, truncation, max_weight=100.0, min_weight=1.0e-3):
+        L = lib()
+        L.oracle_tsdf_create.restype = ctypes.c_void_p
+        L.oracle_tsdf_size.restype = ctypes.c_size_t
+        self.voxel_size, self.truncation = float(voxel_size), float(truncation)
+        self._h = ctypes.c_void_p(L.oracle_tsdf_create(
+            ctypes.c_double(voxel_size), ctypes.c_double(truncation), ctypes.c_double(max_weight),
+            ctypes.c_double(min_weight)))
+
+    def __del__(self):
+        try:
+            lib().oracle_tsdf_free(self._h)
+        except Exception:
+            pass
+
+    def integrate(self, points_world, confidences, cam_origin, step_scale=0.5):
+        pts = _c(points_world, np.float32).reshape(-1, 3)
+        conf = _c(confidences, np.float64).reshape(-1)
+        org = _c(cam_origin, np.float32).reshape(3)
+        if pts.size == 0:
+            return 0
+        lib().oracle_tsdf_integrate.restype = ctypes.c_int
+        return lib().oracle_tsdf_integrate(self._h, _p(pts), _p(conf), _p(org), _ci(pts.shape[0]),
+                                           ctypes.c_double(step_scale))
+
+    def voxels(self):
+        """(keys i64[n,3], tsdf f64[n], weight f64[n]) sorted lexicographically by key."""
+        n = lib().oracle_tsdf_size(self._h)
+        keys = np.zeros((n, 3), np.int64); t = np.zeros(n); w = np.zeros(n)
+        if n:
+            lib().oracle_tsdf_dump(self._h, _p(keys), _p(t), _p(w))
+            o = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+            keys, t, w = keys[o], t[o], w[o]
+        return keys, t, w
+
+    def query(self, points):
+        """Vectorised query: (value f64[n], grad f64[n,3], status u8[n]); status 0 None/None,
+        1 value only, 2 value+gradient."""
+        pts = _c(points, np.float32).reshape(-1, 3)
+        n = pts.shape[0]
+        val = np.zeros(n); g = np.zeros((n, 3)); st = np.zeros(n, np.uint8)
+        lib().oracle_tsdf_query(self._h, _p(pts), _ci(n), _p(val), _p(g), _p(st))
+        return val, g, st
+
+    def pose_system(self, points_world, conf, lam):
+        pts = _c(points_world, np.float32).reshape(-1, 3)
+        cf = _c(conf, np.float32).reshape(-1)
+        H = np.zeros((7, 7)); b = np.zeros(7)
+        lib().oracle_tsdf_pose_system.restype = ctypes.c_int
+        used = lib().oracle_tsdf_pose_system(self._h, _p(pts), _p(cf), _ci(pts.shape[0]), ctypes.c_double(lam),
+                                             _p(H), _p(b))
+        return H, b, used

@@ -133,6 +133,66 @@ def section_tracker():
 SECTIONS["tracker"] = section_tracker
 
 
+def _tsdf_inputs():
+    """Two keyframes of a small synthetic room, world-space points + confidences + camera origins."""
+    from mast3r_slam import synthetic
+
+    out = []
+    for kf, k in enumerate((0, 12)):
+        T = synthetic.camera_pose(k)
+        X = synthetic.render_pointmap(T, 24, 32).reshape(-1, 3)
+        rng = np.random.default_rng(100 + kf)
+        sel = rng.permutation(X.shape[0])[:400]
+        pw = synthetic.sim3_act(T, X[sel]).astype(np.float32)
+        conf = rng.uniform(0.5, 30.0, sel.shape[0]).astype(np.float32).astype(np.float64)  # big: saturates 100
+        out.append((pw, conf, T[:3].astype(np.float32)))
+    return out
+
+
+def section_tsdf_global():
+    """TSDFVolume.integrate / query / gradient and the TSDF pose normal equations, by running the
+    reference's tsdf/global_volume.py and tsdf/tsdf_optimizer.py (loaded by file path)."""
+    import types
+
+    sys.modules.setdefault("lietorch", types.SimpleNamespace(Sim3=object))
+    gv = load_by_path("ref_global_volume", f"{REF}/mast3r_slam/tsdf/global_volume.py")
+    to = load_by_path("ref_tsdf_optimizer", f"{REF}/mast3r_slam/tsdf/tsdf_optimizer.py")
+    vol = gv.TSDFVolume(voxel_size=0.03, truncation=0.12, max_weight=100.0, min_weight=1.0e-3)
+    data = _tsdf_inputs()
+    save = {}
+    for kf, (pw, conf, org) in enumerate(data):
+        fused = vol.integrate(pw, conf, org)
+        keys = np.array(sorted(vol._voxels.keys()), np.int64)
+        save[f"kf{kf}_points"] = pw; save[f"kf{kf}_conf"] = conf; save[f"kf{kf}_origin"] = org
+        save[f"kf{kf}_fused"] = fused
+        save[f"kf{kf}_keys"] = keys
+        save[f"kf{kf}_tsdf"] = np.array([float(vol._voxels[tuple(k)].tsdf) for k in keys])
+        save[f"kf{kf}_weight"] = np.array([float(vol._voxels[tuple(k)].weight) for k in keys])
+    # queries: the integrated points themselves, jittered, plus far-away misses
+    rng = np.random.default_rng(5)
+    q = np.concatenate([data[0][0][:150] + rng.normal(0, 0.02, (150, 3)).astype(np.float32),
+                        data[1][0][:150], np.full((4, 3), 50.0, np.float32)]).astype(np.float32)
+    val = np.zeros(len(q)); grad = np.zeros((len(q), 3)); st = np.zeros(len(q), np.uint8)
+    for i, p in enumerate(q):
+        v, g = vol.query(p)
+        if v is not None:
+            val[i] = float(v); st[i] = 1
+            if g is not None:
+                grad[i] = g; st[i] = 2
+    save.update(query_points=q, query_value=val, query_grad=grad, query_status=st)
+    opt = to.TSDFPoseOptimizer(vol, None, {"lambda": 0.15}, False, "cpu")
+    qconf = rng.uniform(0.05, 3.0, len(q)).astype(np.float32)
+    res, jac, wts = opt._build_linear_system(q, qconf)
+    H, b = opt._accumulate_system(res, jac, wts)
+    save.update(pose_conf=qconf, pose_H=H, pose_b=b, pose_used=len(res))
+    np.savez_compressed(os.path.join(HERE, "tsdf_global.npz"), **save, **meta())
+    print("tsdf_global.npz voxels:", len(keys), "saturated:", int((save["kf1_weight"] >= 100).sum()),
+          "query status counts:", np.bincount(st, minlength=3))
+
+
+SECTIONS["tsdf_global"] = section_tsdf_global
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s in todo:
