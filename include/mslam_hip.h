@@ -148,6 +148,49 @@ int mslam_sim3_act(const float* T, const float* X, float* Y, int num_poses, long
 int mslam_sim3_op(int op, const float* A, const float* B, float* out, int n, int bcast_a, int bcast_b,
                   void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Global sparse TSDF (world-space half of the "dual TSDF"): GPU voxel hash replacing the python
+ * dict of mast3r_slam/tsdf/global_volume.py.  `table` is a caller-owned device buffer of
+ * mslam_tsdf_table_bytes(capacity) bytes (capacity = power of two slots); voxel keys are the
+ * reference's integer triples floor(p / voxel_size) (global_volume.py:133-134), bit-exact.
+ * ------------------------------------------------------------------------------------------ */
+size_t mslam_tsdf_table_bytes(uint64_t capacity);
+int mslam_tsdf_table_init(void* table, size_t table_bytes, uint64_t capacity, void* stream);
+
+/* Replaces TSDFVolume.integrate (global_volume.py:35-72) + _update_voxel (:74-88).
+ * points_world f32[n,3], conf f64[n], cam_origin f32[3] (all device).  Samples are replayed per
+ * voxel in the reference's order, so results equal the sequential python loop, including the
+ * first-touch and max_weight-saturation behaviour.  shard_id/num_shards: only voxels whose key
+ * hashes to this shard are touched (multi-GPU: one table per rank, points replicated). */
+size_t mslam_tsdf_integrate_workspace_bytes(int n_points, double voxel_size, double trunc, double step_scale);
+int mslam_tsdf_integrate(void* table, uint64_t capacity, const float* points_world, const double* conf,
+                         const float* cam_origin, int n_points, double voxel_size, double trunc,
+                         double max_weight, double step_scale, int shard_id, int num_shards,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* out8_host <- {voxels, overflow flag, records of last integrate, voxels touched, points fused
+ * (integrate's return value), dump cursor, capacity lo, capacity hi}.  SYNCHRONISES the stream. */
+int mslam_tsdf_header(void* table, uint64_t capacity, uint32_t* out8_host, void* stream);
+
+/* Dict contents (TSDFVolume._voxels): keys i64[max_out,3], tsdf f64, weight f64, unordered. */
+int mslam_tsdf_dump(void* table, uint64_t capacity, int64_t* keys, double* tsdf, double* weight,
+                    uint32_t max_out, void* stream);
+
+/* Replaces TSDFVolume.query + _estimate_gradient (global_volume.py:93-128) for n points:
+ * status 0 = (None, None), 1 = (value, None), 2 = (value, unit gradient). */
+int mslam_tsdf_query(void* table, uint64_t capacity, const float* points, int n, double voxel_size,
+                     double min_weight, double* value, double* grad, uint8_t* status, void* stream);
+
+/* Replaces one iteration of TSDFPoseOptimizer._optimize_single (tsdf_optimizer.py:77-86):
+ * world = pose.act(points) (if points_in_camera_frame), residual/Jacobian/weights
+ * (_build_linear_system :94-105, _sim3_jacobian :118-124), H,b (_accumulate_system :107-116, fp64),
+ * and if update_pose: delta = solve(H + damping I, -b); pose <- exp(delta) * pose.
+ * H_out f64[7,7], b_out f64[7], used_out i32 may be NULL.  workspace >= 64*36*8 bytes. */
+int mslam_tsdf_pose_step(void* table, uint64_t capacity, const float* points, const float* conf, int n,
+                         float* pose, int points_in_camera_frame, double voxel_size, double min_weight,
+                         double lambda, double damping, int update_pose, double* H_out, double* b_out,
+                         int* used_out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

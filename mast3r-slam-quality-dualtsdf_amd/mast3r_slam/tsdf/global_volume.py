@@ -1,0 +1,114 @@
+"""Mirror of mast3r_slam/tsdf/global_volume.py (TSDFVolume, lines 15-140) on a GPU voxel hash.
+
+Same constructor and method names (`integrate`, `query`, `stats`); the python dict
+`_voxels[(ix,iy,iz)] -> (tsdf, weight)` becomes an open-addressing table in HBM
+(libmslam_hip.so: csrc/tsdf_global.hip).  Inputs may be numpy arrays (as the reference's callers
+pass, global_manager.py:101-106) or device tensors; they are moved to the device once.
+The per-voxel replay makes results independent of thread scheduling and equal to the reference's
+sequential loop; integer keys are bit-exact.  Thread safety: calls are stream-ordered; the
+reference's RLock (global_volume.py:30) has no equivalent because there is no host-side state.
+"""
+import numpy as np
+import torch
+
+import mslam_hip as _m
+
+
+class TSDFVolume:
+    def __init__(self, voxel_size, truncation, max_weight=100.0, min_weight=1.0e-3, capacity=1 << 22,
+                 device="cuda", shard_id=0, num_shards=1):
+        self.voxel_size = float(voxel_size)
+        self.truncation = float(truncation)
+        self.max_weight = float(max_weight)
+        self.min_weight = float(min_weight)
+        self.capacity = int(capacity)
+        self.device = torch.device(device)
+        self.shard_id, self.num_shards = int(shard_id), int(num_shards)
+        L = _m.lib()
+        nbytes = L.mslam_tsdf_table_bytes(self.capacity)
+        if nbytes == 0:
+            raise RuntimeError("TSDFVolume: capacity must be a power of two")
+        self._table = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._ws = None
+        _m.check(L.mslam_tsdf_table_init(_m.ptr(self._table), nbytes, self.capacity, _m.stream_ptr()), "tsdf_table_init")
+
+    # ------------------------------------------------------------------
+    def _dev(self, a, dtype):
+        if isinstance(a, np.ndarray):
+            a = torch.from_numpy(np.ascontiguousarray(a))
+        return a.to(device=self.device, dtype=dtype).contiguous()
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _header(self):
+        out = (np.zeros(8, np.uint32))
+        _m.check(_m.lib().mslam_tsdf_header(_m.ptr(self._table), self.capacity, out.ctypes.data, _m.stream_ptr()),
+                 "tsdf_header")
+        return out
+
+    # ------------------------------------------------------------------
+    def integrate(self, points_world, confidences, cam_origin, step_scale=0.5, return_fused=True):
+        """global_volume.py:35-72.  Returns the number of fused points (needs one stream sync; pass
+        return_fused=False inside a pipeline to stay asynchronous)."""
+        pts = self._dev(points_world, torch.float32).reshape(-1, 3)
+        n = pts.shape[0]
+        if n == 0:
+            return 0
+        conf = self._dev(confidences, torch.float64).reshape(-1)
+        org = self._dev(cam_origin, torch.float32).reshape(3)
+        L = _m.lib()
+        ws = self._workspace(L.mslam_tsdf_integrate_workspace_bytes(n, self.voxel_size, self.truncation, step_scale))
+        rc = L.mslam_tsdf_integrate(
+            _m.ptr(self._table), self.capacity, _m.ptr(pts), _m.ptr(conf), _m.ptr(org), n, self.voxel_size,
+            self.truncation, self.max_weight, float(step_scale), self.shard_id, self.num_shards, _m.ptr(ws),
+            ws.numel(), _m.stream_ptr())
+        _m.check(rc, "tsdf_integrate")
+        if not return_fused:
+            return None
+        h = self._header()
+        if h[1]:
+            raise RuntimeError(f"TSDFVolume: voxel table overflow (code {h[1]}); raise capacity (now {self.capacity})")
+        return int(h[4])
+
+    def query(self, point_world):
+        """global_volume.py:93-105 for one point: (tsdf or None, unit gradient (3,) f64 or None)."""
+        v, g, st = self.query_batch(np.asarray(point_world, np.float32).reshape(1, 3))
+        st = int(st[0])
+        if st == 0:
+            return None, None
+        return float(v[0]), (g[0].cpu().numpy() if st == 2 else None)
+
+    def query_batch(self, points):
+        """Vectorised form: (value f64[n], grad f64[n,3], status u8[n]) device tensors;
+        status 0 = (None, None), 1 = (value, None), 2 = (value, gradient)."""
+        pts = self._dev(points, torch.float32).reshape(-1, 3)
+        n = pts.shape[0]
+        val = torch.zeros(n, dtype=torch.float64, device=self.device)
+        grad = torch.zeros((n, 3), dtype=torch.float64, device=self.device)
+        st = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        rc = _m.lib().mslam_tsdf_query(_m.ptr(self._table), self.capacity, _m.ptr(pts), n, self.voxel_size,
+                                       self.min_weight, _m.ptr(val), _m.ptr(grad), _m.ptr(st), _m.stream_ptr())
+        _m.check(rc, "tsdf_query")
+        return val, grad, st
+
+    def voxels(self):
+        """Dict contents as sorted arrays: keys i64[n,3] (lexicographic), tsdf f64[n], weight f64[n]."""
+        n = int(self._header()[0])
+        keys = torch.zeros((max(n, 1), 3), dtype=torch.int64, device=self.device)
+        t = torch.zeros(max(n, 1), dtype=torch.float64, device=self.device)
+        w = torch.zeros(max(n, 1), dtype=torch.float64, device=self.device)
+        rc = _m.lib().mslam_tsdf_dump(_m.ptr(self._table), self.capacity, _m.ptr(keys), _m.ptr(t), _m.ptr(w),
+                                      max(n, 1), _m.stream_ptr())
+        _m.check(rc, "tsdf_dump")
+        m = int(self._header()[5])
+        keys, t, w = keys[:m].cpu().numpy(), t[:m].cpu().numpy(), w[:m].cpu().numpy()
+        o = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+        return keys[o], t[o], w[o]
+
+    def stats(self):
+        """global_volume.py:136-140."""
+        keys, t, w = self.voxels()
+        return {"valid_voxels": int((w >= self.min_weight).sum()), "total_voxels": int(len(w))}

@@ -1,0 +1,55 @@
+"""Mirror of mast3r_slam/tsdf/tsdf_optimizer.py (TSDFPoseOptimizer, lines 9-124): Sim3 pose
+refinement of a keyframe against the global TSDF.  The per-point python loops (query, Jacobian,
+outer products) and the 7x7 solve run as two kernels per iteration with no host round trip."""
+import torch
+
+import mslam_hip as _m
+from lietorch_hip import Sim3
+
+
+class TSDFPoseOptimizer:
+    def __init__(self, volume, keyframes, cfg, use_calib, device):
+        self.volume = volume
+        self.keyframes = keyframes
+        self.cfg = cfg
+        self.use_calib = use_calib
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self.samples_per_kf = int(cfg.get("samples_per_kf", 2000))
+        self.min_conf = float(cfg.get("min_confidence", 0.05))
+        self.max_iterations = int(cfg.get("max_iterations", 3))
+        self.lambda_tsdf = float(cfg.get("lambda", 0.1))
+        self.damping = float(cfg.get("damping", 1.0e-4))
+        self.pre_icp_iters = int(cfg.get("pre_icp_iters", 0))
+        self._ws = torch.empty(64 * 36 * 8, dtype=torch.uint8, device=volume.device)
+
+    def normal_equations(self, points_world, conf):
+        """_build_linear_system + _accumulate_system (tsdf_optimizer.py:94-116) for world points:
+        returns (H f64[7,7], b f64[7], used i32) device tensors."""
+        v = self.volume
+        pts = v._dev(points_world, torch.float32).reshape(-1, 3)
+        cf = v._dev(conf, torch.float32).reshape(-1)
+        H = torch.zeros((7, 7), dtype=torch.float64, device=v.device)
+        b = torch.zeros(7, dtype=torch.float64, device=v.device)
+        used = torch.zeros(1, dtype=torch.int32, device=v.device)
+        rc = _m.lib().mslam_tsdf_pose_step(
+            _m.ptr(v._table), v.capacity, _m.ptr(pts), _m.ptr(cf), pts.shape[0], 0, 0, v.voxel_size, v.min_weight,
+            self.lambda_tsdf, self.damping, 0, _m.ptr(H), _m.ptr(b), _m.ptr(used), _m.ptr(self._ws),
+            self._ws.numel(), _m.stream_ptr())
+        _m.check(rc, "tsdf_pose_step")
+        return H, b, used
+
+    def refine_pose(self, pose: Sim3, pts_cam, conf, iterations=None):
+        """The iteration loop of _optimize_single (tsdf_optimizer.py:76-86) for already-sampled
+        camera-frame points: pose <- exp(delta) * pose, `iterations` times.  Returns the new Sim3."""
+        v = self.volume
+        iterations = self.max_iterations if iterations is None else iterations
+        pts = v._dev(pts_cam, torch.float32).reshape(-1, 3)
+        cf = v._dev(conf, torch.float32).reshape(-1)
+        data = pose.data.reshape(8).to(device=v.device, dtype=torch.float32).clone()
+        for _ in range(iterations):
+            rc = _m.lib().mslam_tsdf_pose_step(
+                _m.ptr(v._table), v.capacity, _m.ptr(pts), _m.ptr(cf), pts.shape[0], _m.ptr(data), 1, v.voxel_size,
+                v.min_weight, self.lambda_tsdf, self.damping, 1, 0, 0, 0, _m.ptr(self._ws), self._ws.numel(),
+                _m.stream_ptr())
+            _m.check(rc, "tsdf_pose_step")
+        return Sim3(data.reshape(1, 8))

@@ -36,8 +36,19 @@ _SIGNATURES = {
     "mslam_gn_status": [_c_vp] + [_c_int] * 3 + [_c_vp, _c_size, _c_vp],
     "mslam_sim3_act": [_c_vp] * 3 + [_c_int, ctypes.c_longlong, _c_int, _c_vp],
     "mslam_sim3_op": [_c_int] + [_c_vp] * 3 + [_c_int] * 3 + [_c_vp],
+    "mslam_tsdf_table_init": [_c_vp, _c_size, ctypes.c_uint64, _c_vp],
+    "mslam_tsdf_integrate": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp, _c_vp, _c_int] + [_c_double] * 4 + [_c_int, _c_int, _c_vp, _c_size, _c_vp],
+    "mslam_tsdf_header": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp],
+    "mslam_tsdf_dump": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp, _c_vp, ctypes.c_uint32, _c_vp],
+    "mslam_tsdf_query": [_c_vp, ctypes.c_uint64, _c_vp, _c_int, _c_double, _c_double, _c_vp, _c_vp, _c_vp, _c_vp],
+    "mslam_tsdf_pose_step": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp, _c_int, _c_vp, _c_int] + [_c_double] * 4 + [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_size, _c_vp],
 }
-_RESTYPES = {"mslam_last_error": ctypes.c_char_p, "mslam_gn_workspace_bytes": ctypes.c_size_t}
+_RESTYPES = {
+    "mslam_last_error": ctypes.c_char_p,
+    "mslam_gn_workspace_bytes": ctypes.c_size_t,
+    "mslam_tsdf_table_bytes": ctypes.c_size_t,
+    "mslam_tsdf_integrate_workspace_bytes": ctypes.c_size_t,
+}
 
 _lib = None
 
@@ -64,6 +75,10 @@ def lib() -> ctypes.CDLL:
         handle.mslam_last_error.restype = ctypes.c_char_p
         handle.mslam_gn_workspace_bytes.argtypes = [_c_int] * 3
         handle.mslam_gn_workspace_bytes.restype = ctypes.c_size_t
+        handle.mslam_tsdf_table_bytes.argtypes = [ctypes.c_uint64]
+        handle.mslam_tsdf_table_bytes.restype = ctypes.c_size_t
+        handle.mslam_tsdf_integrate_workspace_bytes.argtypes = [_c_int, _c_double, _c_double, _c_double]
+        handle.mslam_tsdf_integrate_workspace_bytes.restype = ctypes.c_size_t
         _lib = handle
     return _lib
 
