@@ -193,6 +193,56 @@ def section_tsdf_global():
 SECTIONS["tsdf_global"] = section_tsdf_global
 
 
+def section_network():
+    """MASt3R two-view forward of the REFERENCE model classes (thirdparty/mast3r, importable on CPU)
+    at a reduced width/depth, with weights overwritten by oracle.mast3r_ref.init_state_dict(seed) so
+    that no weight file needs to be committed: the fixture holds inputs + reference outputs only."""
+    sys.path.insert(0, f"{REF}/thirdparty/mast3r")
+    import mast3r.utils.path_to_dust3r  # noqa: F401
+    from mast3r.model import AsymmetricMASt3R
+
+    sys.path.insert(0, ROOT)
+    from oracle import mast3r_ref as R
+
+    inf = float("inf")
+    cfg = R.Mast3rConfig(enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=12, dec_heads=2)
+    model = AsymmetricMASt3R(
+        pos_embed="RoPE100", patch_embed_cls="PatchEmbedDust3R", img_size=(512, 512), head_type="catmlp+dpt",
+        output_mode="pts3d+desc24", depth_mode=("exp", -inf, inf), conf_mode=("exp", 1, inf),
+        enc_embed_dim=cfg.enc_dim, enc_depth=cfg.enc_depth, enc_num_heads=cfg.enc_heads,
+        dec_embed_dim=cfg.dec_dim, dec_depth=cfg.dec_depth, dec_num_heads=cfg.dec_heads, two_confs=True,
+        desc_conf_mode=("exp", 0, inf), landscape_only=False).eval()
+    sd = R.init_state_dict(cfg, seed=1234)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    # layer{n}_rn are aliases of layer_rn.{n-1} (same Parameter objects, dpt_block.py:68-73)
+    assert all(k == "mask_token" or "_rn.weight" in k for k in missing), missing
+    H, W = 48, 64
+    g = torch.Generator().manual_seed(7)
+    img1 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    img2 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    ts = torch.tensor([[H, W]])
+    with torch.inference_mode():
+        f1, p1, _ = model._encode_image(img1, ts)
+        f2, p2, _ = model._encode_image(img2, ts)
+        dec1, dec2 = model._decoder(f1, p1, f2, p2)
+        dec1, dec2 = list(dec1), list(dec2)
+        r1 = model._downstream_head(1, [t.float() for t in dec1], ts)
+        r2 = model._downstream_head(2, [t.float() for t in dec2], ts)
+    out = dict(img1=img1.numpy(), img2=img2.numpy(), feat1=f1.numpy(), feat2=f2.numpy(), pos1=p1.numpy(),
+               dec1_last=dec1[-1].numpy(), dec2_last=dec2[-1].numpy(), dec1_6=dec1[6].numpy(),
+               cfg=np.array([cfg.enc_dim, cfg.enc_depth, cfg.enc_heads, cfg.dec_dim, cfg.dec_depth, cfg.dec_heads]),
+               seed=1234)
+    for h, r in ((1, r1), (2, r2)):
+        for k in ("pts3d", "conf", "desc", "desc_conf"):
+            out[f"head{h}_{k}"] = r[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "mast3r_small.npz"), **out, **meta())
+    print("mast3r_small.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+SECTIONS["network"] = section_network
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s in todo:
