@@ -191,6 +191,38 @@ int mslam_tsdf_pose_step(void* table, uint64_t capacity, const float* points, co
                          double lambda, double damping, int update_pose, double* H_out, double* b_out,
                          int* used_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MASt3R two-view forward.  Replaces the three model methods the SLAM front/back-end call
+ * (mast3r_slam/mast3r_utils.py:34-40,57-64,74): model._encode_image, model._decoder,
+ * model._downstream_head (thirdparty/mast3r/dust3r/dust3r/model.py:127-139,171-196;
+ * mast3r/catmlp_dpt_head.py:71-96).  bf16 MFMA operands, fp32 accumulate / residual / softmax.
+ *
+ * create: cfg9 = {enc_dim, enc_depth, enc_heads, dec_dim, dec_depth, dec_heads, patch, desc_dim,
+ * dpt_feature_dim}; weight_ptrs = DEVICE pointers in the canonical order documented in
+ * mast3r_slam/mast3r_model.py::canonical_weights (matrices bf16 [out,in] with conv kernels
+ * re-laid-out tap-major, biases / LayerNorm / last 1x1 conv fp32), weight_numels their element
+ * counts (validated).  The model keeps the pointers; the caller keeps the tensors alive.
+ * SYNCHRONISES the stream once (RoPE table upload).
+ * ------------------------------------------------------------------------------------------ */
+int mslam_mast3r_create(void** handle_out, const int* cfg9_host, void* const* weight_ptrs_host,
+                        const long long* weight_numels_host, int n_weights, void* stream);
+int mslam_mast3r_destroy(void* handle);
+size_t mslam_mast3r_workspace_bytes(void* handle, int batch, int H, int W);
+
+/* _encode_image: img f32[B,3,H,W] (ImgNorm range) -> feat f32[B, (H/16)(W/16), enc_dim]
+ * (enc_norm output).  pos is implicit: token n = (y = n / (W/16), x = n % (W/16)). */
+int mslam_mast3r_encode(void* handle, const float* img, int batch, int H, int W, float* feat_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* _decoder + both _downstream_head calls of mast3r_utils.decoder (mast3r_utils.py:34-40):
+ * feat1, feat2 f32[B,N,enc_dim] -> for side s in {1,2}: X f32[B,H,W,3] (pts3d), C f32[B,H,W]
+ * (conf), D f32[B,H,W,desc_dim] (desc), Q f32[B,H,W] (desc_conf).  dec_last1/2 (may be NULL):
+ * f32[B,N,dec_dim] = dec_norm'ed last decoder tokens (for tests). */
+int mslam_mast3r_decode(void* handle, const float* feat1, const float* feat2, int batch, int H, int W,
+                        float* X1, float* C1, float* D1, float* Q1, float* X2, float* C2, float* D2,
+                        float* Q2, float* dec_last1, float* dec_last2, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,52 @@
+// bf16 MFMA GEMM for gfx950 with fused prologue/epilogue, the work-horse of the MASt3R forward.
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )      fp32 accumulate (v_mfma_f32_32x32x16_bf16)
+// A is either a dense row-major bf16 matrix or an implicit im2col view of an NHWC bf16 tensor
+// (3x3 / 1x1 convolution, stride 1 or 2, zero padding) - no im2col buffer is ever materialised.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mslam {
+
+typedef __bf16 bf16;
+
+enum GemmAct { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+enum GemmKind { KIND_NONE = 0, KIND_F32 = 1, KIND_BF16 = 2 };
+enum GemmEpi {
+  EPI_PLAIN = 0,      // out[m*ldc + n]
+  EPI_ATTN = 1,       // attention projection: RoPE2D + head split (q,k -> [B,H,Ntok,64]; v -> [B,H,64,Ntok])
+  EPI_CONVT = 2,      // ConvTranspose2d with kernel == stride: pixel scatter into NHWC
+};
+
+struct GemmArgs {
+  const bf16* A;
+  const bf16* W;  // [N, K] row-major
+  int M, N, K;
+  int lda;
+  // implicit-conv view of A (a_conv != 0): NHWC input [B, cH, cW, cC], k = tap*cC + c
+  int a_conv, cH, cW, cC, cKs, cStride, cPad, cHo, cWo;
+  int a_relu;  // ReLU applied to A on load (pre-activation of the DPT residual units)
+  // epilogue
+  const float* bias;
+  int act;
+  const void* res1; int res1_kind; int ldr1;
+  const void* res2; int res2_kind; int ldr2;
+  void* out; int out_kind; int ldc;
+  int epi;
+  // EPI_ATTN
+  bf16* q_out; bf16* k_out; bf16* vt_out;
+  int sec_base;      // section id of column 0 (0 q, 1 k, 2 v); sections are `sec_dim` columns wide
+  int sec_dim;       // heads * 64
+  int heads;
+  int ntok;          // tokens per image (rows per batch element)
+  int tok_w;         // tokens per image row (RoPE x period)
+  int kv_ntok;       // tokens per image of the k/v side (== ntok for self attention)
+  const float* rope_cos; const float* rope_sin;  // [max_pos][16]
+  float q_scale;
+  // EPI_CONVT
+  int ct_s, ct_cout, ct_h, ct_w;
+};
+
+int launch_gemm(const GemmArgs& a, hipStream_t stream);
+
+}  // namespace mslam

@@ -1,0 +1,165 @@
+"""Mirror of the reference's mast3r_slam/mast3r_utils.py (lines 14-278): same function names, argument
+order and return tuples; the model object is mast3r_slam.mast3r_model.Mast3rHIP and matching is
+mast3r_slam.matching (both libmslam_hip.so).  Retrieval (load_retriever) is out of scope."""
+import numpy as np
+import torch
+
+import mast3r_slam.matching as matching
+from mast3r_slam.config import config
+from mast3r_slam.mast3r_model import Mast3rConfig, Mast3rHIP, load_mast3r_state_dict
+
+
+def load_mast3r(path=None, device="cuda"):
+    """mast3r_utils.py:14-21."""
+    weights_path = "checkpoints/MASt3R_ViTLarge_BaseDecoder_512_catmlpdpt_metric.pth" if path is None else path
+    return Mast3rHIP(load_mast3r_state_dict(weights_path), Mast3rConfig(), device=device)
+
+
+def _hw(shape):
+    s = shape[0] if (hasattr(shape, "ndim") and shape.ndim == 2) or isinstance(shape[0], (list, tuple)) else shape
+    return int(s[0]), int(s[1])
+
+
+@torch.inference_mode()
+def decoder(model, feat1, feat2, pos1, pos2, shape1, shape2):
+    """mast3r_utils.py:34-40: _decoder + both _downstream_head calls (one native call here)."""
+    H, W = _hw(shape1)
+    res1, res2 = model.decode_pair(feat1, feat2, H, W)
+    return res1, res2
+
+
+def downsample(X, C, D, Q):
+    """mast3r_utils.py:43-52."""
+    ds = config["dataset"]["img_downsample"]
+    if ds > 1:
+        X = X[..., ::ds, ::ds, :].contiguous()
+        C = C[..., ::ds, ::ds].contiguous()
+        D = D[..., ::ds, ::ds, :].contiguous()
+        Q = Q[..., ::ds, ::ds].contiguous()
+    return X, C, D, Q
+
+
+def _ensure_feat(model, frame):
+    if frame.feat is None:
+        frame.feat, frame.pos, _ = model._encode_image(frame.img, frame.img_true_shape)
+
+
+def _stack(res):
+    X, C, D, Q = zip(*[(r["pts3d"][0], r["conf"][0], r["desc"][0], r["desc_conf"][0]) for r in res])
+    return torch.stack(X), torch.stack(C), torch.stack(D), torch.stack(Q)
+
+
+@torch.inference_mode()
+def mast3r_symmetric_inference(model, frame_i, frame_j):
+    """mast3r_utils.py:55-79 -> X,C,D,Q stacked [ii, ji, jj, ij]."""
+    _ensure_feat(model, frame_i)
+    _ensure_feat(model, frame_j)
+    res11, res21 = decoder(model, frame_i.feat, frame_j.feat, frame_i.pos, frame_j.pos, frame_i.img_true_shape,
+                           frame_j.img_true_shape)
+    res22, res12 = decoder(model, frame_j.feat, frame_i.feat, frame_j.pos, frame_i.pos, frame_j.img_true_shape,
+                           frame_i.img_true_shape)
+    return downsample(*_stack([res11, res21, res22, res12]))
+
+
+@torch.inference_mode()
+def mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
+    """mast3r_utils.py:83-115.  The reference loops over the B edges in Python (one decoder call per
+    edge and direction); here each direction is ONE batched native call over all B edges."""
+    H, W = _hw(shape_i[0])
+    r11, r21 = model.decode_pair(feat_i, feat_j, H, W)
+    r22, r12 = model.decode_pair(feat_j, feat_i, H, W)
+    order = (r11, r21, r22, r12)
+    X = torch.stack([r["pts3d"] for r in order])      # (4, B, H, W, 3)
+    C = torch.stack([r["conf"] for r in order])
+    D = torch.stack([r["desc"] for r in order])
+    Q = torch.stack([r["desc_conf"] for r in order])
+    return downsample(X, C, D, Q)
+
+
+@torch.inference_mode()
+def mast3r_inference_mono(model, frame):
+    """mast3r_utils.py:118-139 -> (Xii (HW,3), Cii (HW,1))."""
+    _ensure_feat(model, frame)
+    res11, res21 = decoder(model, frame.feat, frame.feat, frame.pos, frame.pos, frame.img_true_shape,
+                           frame.img_true_shape)
+    X, C, D, Q = downsample(*_stack([res11, res21]))
+    return X[0].reshape(-1, 3), C[0].reshape(-1, 1)
+
+
+def mast3r_match_symmetric(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
+    """mast3r_utils.py:142-180."""
+    X, C, D, Q = mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
+    b = X.shape[1]
+    Xii, Xji, Xjj, Xij = X[0], X[1], X[2], X[3]
+    Dii, Dji, Djj, Dij = D[0], D[1], D[2], D[3]
+    Qii, Qji, Qjj, Qij = Q[0], Q[1], Q[2], Q[3]
+    X11 = torch.cat((Xii, Xjj), dim=0)
+    X21 = torch.cat((Xji, Xij), dim=0)
+    D11 = torch.cat((Dii, Djj), dim=0)
+    D21 = torch.cat((Dji, Dij), dim=0)
+    idx_1_to_2, valid_match_2 = matching.match(X11, X21, D11, D21)
+    match_b = X11.shape[0] // 2
+    return (idx_1_to_2[:match_b], idx_1_to_2[match_b:], valid_match_2[:match_b], valid_match_2[match_b:],
+            Qii.reshape(b, -1, 1), Qjj.reshape(b, -1, 1), Qji.reshape(b, -1, 1), Qij.reshape(b, -1, 1))
+
+
+@torch.inference_mode()
+def mast3r_asymmetric_inference(model, frame_i, frame_j):
+    """mast3r_utils.py:183-206."""
+    _ensure_feat(model, frame_i)
+    _ensure_feat(model, frame_j)
+    res11, res21 = decoder(model, frame_i.feat, frame_j.feat, frame_i.pos, frame_j.pos, frame_i.img_true_shape,
+                           frame_j.img_true_shape)
+    return downsample(*_stack([res11, res21]))
+
+
+def mast3r_match_asymmetric(model, frame_i, frame_j, idx_i2j_init=None):
+    """mast3r_utils.py:209-231."""
+    X, C, D, Q = mast3r_asymmetric_inference(model, frame_i, frame_j)
+    b, h, w = X.shape[:-1]
+    b = b // 2
+    Xii, Xji = X[:b], X[b:]
+    Dii, Dji = D[:b], D[b:]
+    idx_i2j, valid_match_j = matching.match(Xii, Xji, Dii, Dji, idx_1_to_2_init=idx_i2j_init)
+    Xii, Xji = X.reshape(2, h * w, 3)
+    Cii, Cji = C.reshape(2, h * w, 1)
+    Qii, Qji = Q.reshape(2, h * w, 1)
+    return idx_i2j, valid_match_j, Xii, Cii, Qii, Xji, Cji, Qji
+
+
+def _resize_pil_image(img, long_edge_size):
+    import PIL.Image
+
+    S = max(img.size)
+    interp = PIL.Image.LANCZOS if S > long_edge_size else PIL.Image.BICUBIC
+    new_size = tuple(int(round(x * long_edge_size / S)) for x in img.size)
+    return img.resize(new_size, interp)
+
+
+def resize_img(img, size, square_ok=False, return_transformation=False):
+    """mast3r_utils.py:244-278 (CPU, PIL): long side -> 512, centre crop to multiples of 16, ImgNorm."""
+    import PIL.Image
+
+    assert size == 224 or size == 512
+    img = PIL.Image.fromarray(np.uint8(img * 255))
+    W1, H1 = img.size
+    if size == 224:
+        img = _resize_pil_image(img, round(size * max(W1 / H1, H1 / W1)))
+    else:
+        img = _resize_pil_image(img, size)
+    W, H = img.size
+    cx, cy = W // 2, H // 2
+    if size == 224:
+        half = min(cx, cy)
+        img = img.crop((cx - half, cy - half, cx + half, cy + half))
+    else:
+        halfw, halfh = ((2 * cx) // 16) * 8, ((2 * cy) // 16) * 8
+        if not square_ok and W == H:
+            halfh = 3 * halfw / 4
+        img = img.crop((cx - halfw, cy - halfh, cx + halfw, cy + halfh))
+    arr = np.asarray(img)
+    norm = (torch.from_numpy(arr.copy()).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5   # ImgNorm
+    res = dict(img=norm[None], true_shape=np.int32([img.size[::-1]]), unnormalized_img=arr)
+    if return_transformation:
+        return res, (W1 / W, H1 / H, (W - img.size[0]) / 2, (H - img.size[1]) / 2)
+    return res

@@ -36,6 +36,10 @@ _SIGNATURES = {
     "mslam_gn_status": [_c_vp] + [_c_int] * 3 + [_c_vp, _c_size, _c_vp],
     "mslam_sim3_act": [_c_vp] * 3 + [_c_int, ctypes.c_longlong, _c_int, _c_vp],
     "mslam_sim3_op": [_c_int] + [_c_vp] * 3 + [_c_int] * 3 + [_c_vp],
+    "mslam_mast3r_create": [_c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_vp],
+    "mslam_mast3r_destroy": [_c_vp],
+    "mslam_mast3r_encode": [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_size, _c_vp],
+    "mslam_mast3r_decode": [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 10 + [_c_vp, _c_size, _c_vp],
     "mslam_tsdf_table_init": [_c_vp, _c_size, ctypes.c_uint64, _c_vp],
     "mslam_tsdf_integrate": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp, _c_vp, _c_int] + [_c_double] * 4 + [_c_int, _c_int, _c_vp, _c_size, _c_vp],
     "mslam_tsdf_header": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp],
@@ -47,6 +51,7 @@ _RESTYPES = {
     "mslam_last_error": ctypes.c_char_p,
     "mslam_gn_workspace_bytes": ctypes.c_size_t,
     "mslam_tsdf_table_bytes": ctypes.c_size_t,
+    "mslam_mast3r_workspace_bytes": ctypes.c_size_t,
     "mslam_tsdf_integrate_workspace_bytes": ctypes.c_size_t,
 }
 
@@ -75,6 +80,8 @@ def lib() -> ctypes.CDLL:
         handle.mslam_last_error.restype = ctypes.c_char_p
         handle.mslam_gn_workspace_bytes.argtypes = [_c_int] * 3
         handle.mslam_gn_workspace_bytes.restype = ctypes.c_size_t
+        handle.mslam_mast3r_workspace_bytes.argtypes = [_c_vp, _c_int, _c_int, _c_int]
+        handle.mslam_mast3r_workspace_bytes.restype = ctypes.c_size_t
         handle.mslam_tsdf_table_bytes.argtypes = [ctypes.c_uint64]
         handle.mslam_tsdf_table_bytes.restype = ctypes.c_size_t
         handle.mslam_tsdf_integrate_workspace_bytes.argtypes = [_c_int, _c_double, _c_double, _c_double]

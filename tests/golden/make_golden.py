@@ -217,7 +217,7 @@ def section_network():
     assert not unexpected, unexpected
     # layer{n}_rn are aliases of layer_rn.{n-1} (same Parameter objects, dpt_block.py:68-73)
     assert all(k == "mask_token" or "_rn.weight" in k for k in missing), missing
-    H, W = 48, 64
+    H, W = 64, 96   # 4 x 6 = 24 tokens (the HIP attention kernel wants a multiple of 8)
     g = torch.Generator().manual_seed(7)
     img1 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
     img2 = torch.rand(1, 3, H, W, generator=g) * 2 - 1

@@ -34,7 +34,7 @@ def test_forward_matches_reference_model(fx):
         np.testing.assert_allclose(d2[-1].numpy(), fx["dec2_last"], atol=5e-5, rtol=1e-4)
         np.testing.assert_allclose(d1[6].numpy(), fx["dec1_6"], atol=5e-5, rtol=1e-4)
         for h, toks in ((1, d1), (2, d2)):
-            r = R.downstream_head(sd, cfg, h, toks, H, W)
+            r = R.downstream_head(sd, cfg, h, toks, int(H), int(W))
             for k in ("pts3d", "conf", "desc", "desc_conf"):
                 a, b = r[k].numpy(), fx[f"head{h}_{k}"]
                 rel = np.linalg.norm(a - b) / np.linalg.norm(b)
