@@ -223,6 +223,24 @@ int mslam_mast3r_decode(void* handle, const float* feat1, const float* feat2, in
                         float* Q2, float* dec_last1, float* dec_last2, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Frame-to-keyframe tracking GN.  Replaces FrameTracker.opt_pose_ray_dist_sim3 /
+ * opt_pose_calib_sim3 + solve (mast3r_slam/tracker.py:208-318; geometry.py:17-104;
+ * nonlinear_optimizer.py:5-33): <= max_iters Gauss-Newton iterations on the relative Sim3
+ * T_CkCf (f32[8] device, updated IN PLACE), residuals between keyframe points Xk f32[n,3] and
+ * T.Xf[idx_f2k] (Xf f32[n,3], idx i64[n]), weights sqrt(Qk) (f32[n]) gated by valid (u8[n]).
+ * use_calib: pixel + log-depth residual with K f32[3,3] (device).  No host sync: convergence
+ * (rel. cost decrease < rel_error or |tau| < delta_norm) is a device flag.  status_out (device,
+ * 32 bytes, may be NULL) <- {i32 done, i32 iters, i32 chol_fail, f32 old_cost, f32 last_cost,
+ * f32 last_delta_norm, -, -}; chol_fail mirrors the exception path of tracker.py:72-93.
+ * ------------------------------------------------------------------------------------------ */
+size_t mslam_track_workspace_bytes(int n_points);
+int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, const float* Xk, const int64_t* idx_f2k,
+                     const float* Qk, const uint8_t* valid, int n_points, const float* K, int width,
+                     int height, float sigma_a, float sigma_b, float huber, int pixel_border, float z_eps,
+                     int max_iters, float rel_error, float delta_norm, void* status_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,182 @@
+"""Mirror of mast3r_slam/global_opt.py (FactorGraph, lines 12-223): edge bookkeeping, symmetric
+matching per edge batch, two-way edge preparation and the calls into the native Gauss-Newton.
+
+Multi-GPU (new; the reference is single-device): when torch.distributed is initialised and
+`shard_edges=True`, each rank accumulates the normal-equation blocks of ITS slice of the directed edges,
+the reference-layout block buffers Hs[4,E,7,7] / gs[2,E,7] are summed with ONE all-reduce per GN
+iteration (RCCL over xGMI on MI355X; other ranks' slots are zero so the sum is exact and every rank
+gets bit-identical blocks), and every rank runs the same fp64 solve + retraction - no broadcast."""
+import torch
+
+import mast3r_slam_backends
+import mslam_hip as _m
+from lietorch_hip import Sim3
+from mast3r_slam.config import config
+from mast3r_slam.geometry import constrain_points_to_ray
+from mast3r_slam.mast3r_utils import mast3r_match_symmetric
+
+
+class FactorGraph:
+    def __init__(self, model, frames, K=None, device="cuda", shard_edges=False):
+        self.model = model
+        self.frames = frames
+        self.device = device
+        self.cfg = config["local_opt"]
+        z = lambda dt: torch.as_tensor([], dtype=dt, device=self.device)
+        self.ii, self.jj = z(torch.long), z(torch.long)
+        self.idx_ii2jj, self.idx_jj2ii = z(torch.long), z(torch.long)
+        self.valid_match_j, self.valid_match_i = z(torch.bool), z(torch.bool)
+        self.Q_ii2jj, self.Q_jj2ii = z(torch.float32), z(torch.float32)
+        self.window_size = self.cfg["window_size"]
+        self.K = K
+        self.last_unique_kf_idx = None
+        self.shard_edges = shard_edges
+
+    # ------------------------------------------------------------------
+    def add_factors(self, ii, jj, min_match_frac, is_reloc=False):
+        """global_opt.py:32-101."""
+        kf_ii = [self.frames[idx] for idx in ii]
+        kf_jj = [self.frames[idx] for idx in jj]
+        feat_i = torch.cat([kf.feat for kf in kf_ii])
+        feat_j = torch.cat([kf.feat for kf in kf_jj])
+        pos_i = torch.cat([kf.pos for kf in kf_ii])
+        pos_j = torch.cat([kf.pos for kf in kf_jj])
+        shape_i = [kf.img_true_shape for kf in kf_ii]
+        shape_j = [kf.img_true_shape for kf in kf_jj]
+        res = mast3r_match_symmetric(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
+        return self.add_matched_factors(ii, jj, *res, min_match_frac=min_match_frac, is_reloc=is_reloc)
+
+    def add_matched_factors(self, ii, jj, idx_i2j, idx_j2i, valid_match_j, valid_match_i, Qii, Qjj, Qji, Qij,
+                            min_match_frac, is_reloc=False):
+        """Second half of add_factors (global_opt.py:56-101): confidence products, match-fraction gate,
+        append.  Split out so that precomputed matches can be injected (bench / tests)."""
+        batch_inds = torch.arange(idx_i2j.shape[0], device=idx_i2j.device)[:, None].repeat(1, idx_i2j.shape[1])
+        Qj = torch.sqrt(Qii[batch_inds, idx_i2j] * Qji)
+        Qi = torch.sqrt(Qjj[batch_inds, idx_j2i] * Qij)
+        valid_j = valid_match_j & (Qj > self.cfg["Q_conf"])
+        valid_i = valid_match_i & (Qi > self.cfg["Q_conf"])
+        nj = valid_j.shape[1] * valid_j.shape[2]
+        ni = valid_i.shape[1] * valid_i.shape[2]
+        match_frac_j = valid_j.sum(dim=(1, 2)) / nj
+        match_frac_i = valid_i.sum(dim=(1, 2)) / ni
+        ii_t = torch.as_tensor(ii, device=self.device)
+        jj_t = torch.as_tensor(jj, device=self.device)
+        invalid = torch.minimum(match_frac_j, match_frac_i) < min_match_frac
+        invalid = (~(ii_t == (jj_t - 1))) & invalid
+        if invalid.any() and is_reloc:
+            return False
+        ok = ~invalid
+        self.ii = torch.cat([self.ii, ii_t[ok]])
+        self.jj = torch.cat([self.jj, jj_t[ok]])
+        self.idx_ii2jj = torch.cat([self.idx_ii2jj, idx_i2j[ok]])
+        self.idx_jj2ii = torch.cat([self.idx_jj2ii, idx_j2i[ok]])
+        self.valid_match_j = torch.cat([self.valid_match_j, valid_match_j[ok]])
+        self.valid_match_i = torch.cat([self.valid_match_i, valid_match_i[ok]])
+        self.Q_ii2jj = torch.cat([self.Q_ii2jj, Qj[ok]])
+        self.Q_jj2ii = torch.cat([self.Q_jj2ii, Qi[ok]])
+        return ok.sum() > 0
+
+    def get_unique_kf_idx(self):
+        return torch.unique(torch.cat([self.ii, self.jj]), sorted=True)
+
+    def prep_two_way_edges(self):
+        """global_opt.py:106-112."""
+        ii = torch.cat((self.ii, self.jj), dim=0)
+        jj = torch.cat((self.jj, self.ii), dim=0)
+        idx_ii2jj = torch.cat((self.idx_ii2jj, self.idx_jj2ii), dim=0)
+        valid_match = torch.cat((self.valid_match_j, self.valid_match_i), dim=0)
+        Q_ii2jj = torch.cat((self.Q_ii2jj, self.Q_jj2ii), dim=0)
+        return ii, jj, idx_ii2jj, valid_match, Q_ii2jj
+
+    def get_poses_points(self, unique_kf_idx):
+        kfs = [self.frames[idx] for idx in unique_kf_idx]
+        Xs = torch.stack([kf.X_canon for kf in kfs])
+        T_WCs = Sim3(torch.stack([kf.T_WC.data for kf in kfs]))
+        Cs = torch.stack([kf.get_average_conf() for kf in kfs])
+        return Xs, T_WCs, Cs
+
+    # ------------------------------------------------------------------
+    def _solve(self, kind):
+        pin = self.cfg["pin"]
+        unique_kf_idx = self.get_unique_kf_idx()
+        if unique_kf_idx.numel() <= pin:
+            self.last_unique_kf_idx = None
+            return
+        Xs, T_WCs, Cs = self.get_poses_points(unique_kf_idx)
+        self.last_unique_kf_idx = unique_kf_idx.detach().cpu()
+        c = self.cfg
+        K = self.K
+        height = width = 0
+        if kind == "calib":
+            img_size = self.frames[0].img.shape[-2:]
+            Xs = constrain_points_to_ray(img_size, Xs, K)
+            height, width = int(img_size[0]), int(img_size[1])
+        ii, jj, idx_ii2jj, valid_match, Q = self.prep_two_way_edges()
+        pose_data = T_WCs.data[:, 0, :].contiguous()
+        Xs, Cs = Xs.contiguous(), Cs.contiguous()
+        if self.shard_edges and torch.distributed.is_available() and torch.distributed.is_initialized():
+            gauss_newton_sharded(kind, pose_data, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, c, height, width)
+        elif kind == "rays":
+            mast3r_slam_backends.gauss_newton_rays(
+                pose_data, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, c["sigma_ray"], c["sigma_dist"], c["C_conf"],
+                c["Q_conf"], c["max_iters"], c["delta_norm"])
+        else:
+            mast3r_slam_backends.gauss_newton_calib(
+                pose_data, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, height, width, c["pixel_border"],
+                c["depth_eps"], c["sigma_pixel"], c["sigma_depth"], c["C_conf"], c["Q_conf"], c["max_iters"],
+                c["delta_norm"])
+        self.frames.update_T_WCs(Sim3(pose_data[:, None, :])[pin:], unique_kf_idx[pin:])
+
+    def solve_GN_rays(self):
+        """global_opt.py:123-164."""
+        self._solve("rays")
+
+    def solve_GN_calib(self):
+        """global_opt.py:166-223."""
+        self._solve("calib")
+
+
+def edge_slice(E, rank, world):
+    """Contiguous slice of the E directed edges owned by `rank` (balanced to within one edge)."""
+    base, rem = divmod(E, world)
+    begin = rank * base + min(rank, rem)
+    return begin, base + (1 if rank < rem else 0)
+
+
+def gauss_newton_sharded(kind, Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, cfg, height=0, width=0,
+                         group=None):
+    """The GN loop of gn_kernels.cu:1181-1225 with the edge kernel sharded over ranks.  Per iteration:
+    local accumulate -> all_reduce(sum) of Hs and gs -> replicated solve + retraction.  Twc is updated
+    in place on every rank (identical bits).  Works on any backend torch.distributed offers for the
+    tensors' device ("nccl" = RCCL on ROCm)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    P, HW, E = Xs.shape[0], Xs.shape[1], ii.shape[0]
+    e0, cnt = edge_slice(E, rank, world)
+    dev = Twc.device
+    L = _m.lib()
+    ws = mast3r_slam_backends._workspace(L.mslam_gn_workspace_bytes(P, E, HW), dev)
+    blocks = torch.zeros(4 * E * 49 + 2 * E * 7, dtype=torch.float32, device=dev)  # one buffer, one all-reduce
+    Hs, gs = blocks[: 4 * E * 49], blocks[4 * E * 49:]
+    dx = torch.zeros((P - 1, 7), dtype=torch.float32, device=dev)
+    idx_l = idx_ii2jj[e0:e0 + cnt].contiguous()
+    vm_l = valid_match[e0:e0 + cnt].contiguous()
+    Q_l = Q[e0:e0 + cnt].contiguous()
+    kid = {"rays": 0, "calib": 1, "points": 2}[kind]
+    sa, sb = {"rays": (cfg["sigma_ray"], cfg["sigma_dist"]), "calib": (cfg["sigma_pixel"], cfg["sigma_depth"]),
+              "points": (cfg.get("sigma_point", 0.05), 1.0)}[kind]
+    _m.check(L.mslam_gn_begin(_m.ptr(ii), _m.ptr(jj), P, E, HW, _m.ptr(ws), ws.numel(), _m.stream_ptr()), "gn_begin")
+    for _ in range(int(cfg["max_iters"])):
+        blocks.zero_()
+        rc = L.mslam_gn_accumulate(
+            kid, _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(K) if K is not None else 0, _m.ptr(idx_l), _m.ptr(vm_l),
+            _m.ptr(Q_l), P, HW, E, e0, cnt, float(sa), float(sb), float(cfg["C_conf"]), float(cfg["Q_conf"]),
+            int(height), int(width), int(cfg["pixel_border"]), float(cfg["depth_eps"]), _m.ptr(Hs), _m.ptr(gs),
+            _m.ptr(ws), ws.numel(), _m.stream_ptr())
+        _m.check(rc, "gn_accumulate")
+        dist.all_reduce(blocks, op=dist.ReduceOp.SUM, group=group)
+        rc = L.mslam_gn_solve_retract(_m.ptr(Hs), _m.ptr(gs), P, E, HW, _m.ptr(Twc), _m.ptr(dx),
+                                      float(cfg["delta_norm"]), _m.ptr(ws), ws.numel(), _m.stream_ptr())
+        _m.check(rc, "gn_solve_retract")
+    return dx

@@ -1,0 +1,123 @@
+"""Mirror of mast3r_slam/tracker.py (FrameTracker, lines 15-317): same class, method names and return
+values.  Inference + matching + the whole <=50-iteration Sim3 Gauss-Newton run in libmslam_hip.so; the
+quality-service submission (tracker.py:94-145) is out of scope."""
+import numpy as np
+import torch
+
+import mslam_hip as _m
+from lietorch_hip import Sim3
+from mast3r_slam.config import config
+from mast3r_slam.geometry import constrain_points_to_ray
+from mast3r_slam.mast3r_utils import mast3r_match_asymmetric
+
+
+class FrameTracker:
+    def __init__(self, model, frames, device):
+        self.cfg = config["tracking"]
+        self.model = model
+        self.keyframes = frames
+        self.device = device
+        self.reset_idx_f2k()
+        self._ws = None
+        self._status = None
+
+    def reset_idx_f2k(self):
+        self.idx_f2k = None
+
+    # ------------------------------------------------------------------
+    def track(self, frame):
+        """tracker.py:28-179 -> (new_kf, [Xk, Ck_avg, Xf, Cf_avg, Qkf, Qff], skipped)."""
+        keyframe = self.keyframes.last_keyframe()
+        idx_f2k, valid_match_k, Xff, Cff, Qff, Xkf, Ckf, Qkf = mast3r_match_asymmetric(
+            self.model, frame, keyframe, idx_i2j_init=self.idx_f2k)
+        self.idx_f2k = idx_f2k.clone()
+        idx_f2k = idx_f2k[0]
+        valid_match_k = valid_match_k[0]
+        Qk = torch.sqrt(Qff[idx_f2k] * Qkf)
+        frame.update_pointmap(Xff, Cff)
+
+        use_calib = config["use_calib"]
+        img_size = frame.img.shape[-2:]
+        K = keyframe.K if use_calib else None
+        Xf, Xk, T_WCf, T_WCk, Cf, Ck, meas_k, valid_meas_k = self.get_points_poses(
+            frame, keyframe, idx_f2k, img_size, use_calib, K)
+
+        valid_Cf = Cf > self.cfg["C_conf"]
+        valid_Ck = Ck > self.cfg["C_conf"]
+        valid_Q = Qk > self.cfg["Q_conf"]
+        valid_opt = valid_match_k & valid_Cf & valid_Ck & valid_Q
+        valid_kf = valid_match_k & valid_Q
+
+        match_frac = valid_opt.sum() / valid_opt.numel()
+        if match_frac < self.cfg["min_match_frac"]:
+            return False, [], True
+
+        if not use_calib:
+            T_WCf, T_CkCf, ok = self.opt_pose_ray_dist_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid_opt)
+        else:
+            T_WCf, T_CkCf, ok = self.opt_pose_calib_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, meas_k,
+                                                         valid_meas_k, K, img_size)
+        if not ok:  # "Cholesky failed" (tracker.py:91-93)
+            return False, [], True
+
+        frame.T_WC = T_WCf
+        Xkk = T_CkCf.act(Xkf)
+        keyframe.update_pointmap(Xkk, Ckf)
+        self.keyframes[len(self.keyframes) - 1] = keyframe
+
+        n_valid = valid_kf.sum()
+        match_frac_k = n_valid / valid_kf.numel()
+        unique_frac_f = torch.unique(idx_f2k[valid_match_k[:, 0]]).shape[0] / valid_kf.numel()
+        new_kf = min(match_frac_k, unique_frac_f) < self.cfg["match_frac_thresh"]
+        if new_kf:
+            self.reset_idx_f2k()
+        return (new_kf, [keyframe.X_canon, keyframe.get_average_conf(), frame.X_canon, frame.get_average_conf(),
+                         Qkf, Qff], False)
+
+    def get_points_poses(self, frame, keyframe, idx_f2k, img_size, use_calib, K=None):
+        """tracker.py:181-206.  Unlike the reference this returns the UN-gathered frame points and
+        the index (the gather happens inside the GN kernel); Cf is gathered as in the reference."""
+        Xf, Xk = frame.X_canon, keyframe.X_canon
+        Cf, Ck = frame.get_average_conf(), keyframe.get_average_conf()
+        meas_k = valid_meas_k = None
+        if use_calib:
+            Xf = constrain_points_to_ray(img_size, Xf[None], K).squeeze(0)
+            Xk = constrain_points_to_ray(img_size, Xk[None], K).squeeze(0)
+        self._idx = idx_f2k
+        return Xf, Xk, frame.T_WC, keyframe.T_WC, Cf[idx_f2k], Ck, meas_k, valid_meas_k
+
+    # ------------------------------------------------------------------
+    def _run(self, use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None):
+        cfg = self.cfg
+        dev = Xf.device
+        idx = self._idx if idx is None else idx
+        n = Xk.shape[0]
+        T_rel = (T_WCk.inv() * T_WCf).data.reshape(8).contiguous().clone()
+        L = _m.lib()
+        need = L.mslam_track_workspace_bytes(n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._status = torch.zeros(8, dtype=torch.int32, device=dev)
+        h, w = (int(img_size[0]), int(img_size[1])) if img_size is not None else (0, 0)
+        sa, sb = (cfg["sigma_pixel"], cfg["sigma_depth"]) if use_calib else (cfg["sigma_ray"], cfg["sigma_dist"])
+        rc = L.mslam_track_pose(
+            int(use_calib), _m.ptr(T_rel), _m.ptr(Xf.contiguous()), _m.ptr(Xk.contiguous()), _m.ptr(idx.contiguous()),
+            _m.ptr(Qk.reshape(-1).contiguous()), _m.ptr(valid.reshape(-1).contiguous()), n,
+            _m.ptr(K.contiguous()) if use_calib else 0, w, h, float(sa), float(sb), float(cfg["huber"]),
+            int(cfg["pixel_border"]), float(cfg["depth_eps"]), int(cfg["max_iters"]), float(cfg["rel_error"]),
+            float(cfg["delta_norm"]), _m.ptr(self._status), _m.ptr(self._ws), self._ws.numel(), _m.stream_ptr())
+        _m.check(rc, "track_pose")
+        T_CkCf = Sim3(T_rel.reshape(1, 8))
+        T_WCf_new = T_WCk * T_CkCf
+        st = self._status.cpu()   # the one host sync of the tracking step (the caller needs the verdict)
+        self.last_iters = int(st[1])
+        return T_WCf_new, T_CkCf, int(st[2]) == 0
+
+    def opt_pose_ray_dist_sim3(self, Xf, Xk, T_WCf, T_WCk, Qk, valid, idx=None):
+        """tracker.py:225-266 -> (T_WCf, T_CkCf, ok)."""
+        return self._run(False, Xf, Xk, T_WCf, T_WCk, Qk, valid, None, None, idx)
+
+    def opt_pose_calib_sim3(self, Xf, Xk, T_WCf, T_WCk, Qk, valid, meas_k, valid_meas_k, K, img_size, idx=None):
+        """tracker.py:268-318 -> (T_WCf, T_CkCf, ok).  meas_k / valid_meas_k are derived from Xk inside
+        the kernel (pixel grid + log depth, tracker.py:197-203)."""
+        return self._run(True, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx)
