@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SLAM frames/sec of the per-frame hot path (MASt3R infer + match + TSDF fuse + GN
+solve) on a synthetic 512x384 RGB-D stream (BASELINE.json config 3), N GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE frame through the hot path:
+  tracking   encode(frame) -> asymmetric decode + heads vs the last keyframe -> iterative-projection match
+             + fp16 descriptor refinement -> frame-to-keyframe Sim3 Gauss-Newton
+  every --kf-every-th frame additionally (keyframe / backend):
+             symmetric decode + heads of --edges-per-kf keyframe pairs (both directions, batched),
+             matching of both directions, global Sim3 GN over the keyframe graph, global TSDF integration
+             of 40 000 points + TSDF pose refinement (3 iterations x 2 000 samples)
+The network runs on random-init ViT-L weights of the real architecture (no checkpoint offline); because
+random weights give meaningless geometry, the match / GN / TSDF stages consume seeded synthetic pointmaps
+of the same shapes (back-projected room depth) - every stage does its full work.
+
+Multi-GPU (weak scaling): every rank tracks its own frame stream; the keyframe graph grows with N and its
+directed edges are sharded across ranks with one all-reduce of the normal-equation blocks per GN
+iteration; TSDF voxels are sharded by key hash, keyframe points are all-gathered.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "mast3r-slam-quality-dualtsdf_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+H, W = 384, 512
+GF_TRACK = 1514.1      # GFLOP per tracked frame: encode 523.05 + decoder 437.28 + 2 heads x 276.90
+GF_EDGE = 1982.2       # GFLOP per symmetric keyframe edge: 2 x (decoder + 2 heads)
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--kf-every", type=int, default=8)
+    ap.add_argument("--edges-per-kf", type=int, default=4)
+    ap.add_argument("--graph-kfs", type=int, default=8, help="keyframes in the backend graph PER GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth-scale", type=float, default=1.0, help="debug: <1 shrinks the network depth")
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    return rank, world, torch.device("cuda", local if world > 1 else 0)
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+class Pipeline:
+    """Owns the model, the synthetic pools and one step of the hot path."""
+
+    def __init__(self, args, rank, world, dev):
+        from mast3r_slam import synthetic
+        from mast3r_slam.config import config
+        from mast3r_slam.mast3r_model import Mast3rConfig, Mast3rHIP, random_state_dict
+        from mast3r_slam.tracker import FrameTracker
+        from mast3r_slam.tsdf import TSDFPoseOptimizer, TSDFVolume
+
+        self.args, self.rank, self.world, self.dev = args, rank, world, dev
+        self.cfg = config
+        ds = args.depth_scale
+        mc = Mast3rConfig(enc_depth=max(1, round(24 * ds)), dec_depth=12)
+        self.flop_scale = (523.05 * mc.enc_depth / 24 + 437.28 + 2 * 276.90) / GF_TRACK
+        sd = random_state_dict(mc, seed=0)
+        self.model = Mast3rHIP(sd, mc, device=dev)
+        del sd
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        # RGB frame pool (ImgNorm range) - each rank its own stream segment
+        self.frames = [t(synthetic.render_rgb(synthetic.camera_pose(8 * (rank * 100 + k)), H, W))[None] for k in range(4)]
+        ts = torch.tensor([[H, W]])
+        self.kf_feat = self.model._encode_image(self.frames[0], ts)[0]
+        # geometry pool for matching + tracking: frame i vs keyframe j
+        self.pairs = []
+        for k in range(2):
+            pr = synthetic.make_pair(8 * k + 3, 8 * k, h=H, w=W, seed=rank)
+            Tf, Tk = synthetic.camera_pose(8 * k + 3), synthetic.camera_pose(8 * k)
+            Xk = synthetic.render_pointmap(Tk, H, W).reshape(-1, 3).astype(np.float32)
+            rng = np.random.default_rng(k)
+            xi = rng.normal(0, 0.01, 7)
+            Tf_noisy = Tf.copy(); Tf_noisy[:3] += xi[:3]
+            self.pairs.append(dict(
+                X11=t(pr["X11"])[None], X21=t(pr["X21"])[None], D11=t(pr["D11"])[None], D21=t(pr["D21"])[None],
+                Xf=t(pr["X11"].reshape(-1, 3)), Xk=t(Xk), Qk=t(np.sqrt(pr["Q11"] * pr["Q21"]).reshape(-1, 1)),
+                T_WCf=t(Tf_noisy.astype(np.float32)).reshape(1, 8), T_WCk=t(Tk.astype(np.float32)).reshape(1, 8)))
+        self.tracker = FrameTracker(self.model, None, dev)
+        # backend: symmetric edge batch features (reuse encoded keyframe features), graph, TSDF
+        E = args.edges_per_kf
+        self.feat_i = self.kf_feat.expand(E, -1, -1).contiguous()
+        self.feat_j = self.model._encode_image(self.frames[1], ts)[0].expand(E, -1, -1).contiguous()
+        g = synthetic.make_graph(n_kf=args.graph_kfs * world, h=H, w=W, seed=11, stride=4, extra_edges=2, pose_noise=0.01)
+        self.graph = {k: t(v) for k, v in g.items() if isinstance(v, np.ndarray)}
+        self.vol = TSDFVolume(0.03, 0.12, capacity=1 << 22, device=dev, shard_id=rank, num_shards=world)
+        self.tsdf_opt = TSDFPoseOptimizer(self.vol, None, dict(config["tsdf_global"]), False, dev)
+        Tk = synthetic.camera_pose(8 * rank)
+        Xw = synthetic.sim3_act(Tk, synthetic.render_pointmap(Tk, H, W).reshape(-1, 3))
+        rng = np.random.default_rng(rank)
+        sel = rng.permutation(H * W)[:40000]
+        self.tsdf_pts = t(Xw[sel].astype(np.float32))
+        self.tsdf_conf = t(rng.uniform(0.5, 3.0, 40000))
+        self.tsdf_org = t(Tk[:3].astype(np.float32))
+        self.tsdf_cam_pts = t(synthetic.render_pointmap(Tk, H, W).reshape(-1, 3)[sel[:2000]].astype(np.float32))
+        self.tsdf_cam_conf = t(rng.uniform(0.5, 3.0, 2000).astype(np.float32))
+        self.tsdf_pose = t(Tk.astype(np.float32)).reshape(1, 8)
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.net_ms = 0.0
+        self.net_calls = 0
+        self.timing = False
+
+    def _net(self, fn):
+        """Run a network stage; when timing, bracket it with events on the launch stream."""
+        if not self.timing:
+            return fn()
+        self.ev[0].record()
+        out = fn()
+        self.ev[1].record()
+        self._pending.append((self.ev[0], self.ev[1]))
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        return out
+
+    def step(self, f):
+        from lietorch_hip import Sim3
+        from mast3r_slam import matching
+        import mast3r_slam_backends as be
+
+        a = self.args
+        c = self.cfg
+        img = self.frames[f % len(self.frames)]
+        pr = self.pairs[f % len(self.pairs)]
+        # ---- tracking ---------------------------------------------------------------------------
+        feat = self._net(lambda: self.model._encode_image(img)[0])
+        self._net(lambda: self.model.decode_pair(feat, self.kf_feat, H, W))
+        idx, valid = matching.match(pr["X11"], pr["X21"], pr["D11"], pr["D21"])
+        self.tracker.opt_pose_ray_dist_sim3(pr["Xf"], pr["Xk"], Sim3(pr["T_WCf"]), Sim3(pr["T_WCk"]), pr["Qk"],
+                                            valid[0], idx=idx[0])
+        # ---- keyframe / backend -------------------------------------------------------------------
+        if f % a.kf_every == 0:
+            self._net(lambda: self.model.decode_pair(self.feat_i, self.feat_j, H, W))
+            self._net(lambda: self.model.decode_pair(self.feat_j, self.feat_i, H, W))
+            E = a.edges_per_kf
+            X11 = torch.cat([p["X11"] for p in self.pairs] * E)[: 2 * E]
+            X21 = torch.cat([p["X21"] for p in self.pairs] * E)[: 2 * E]
+            D11 = torch.cat([p["D11"] for p in self.pairs] * E)[: 2 * E]
+            D21 = torch.cat([p["D21"] for p in self.pairs] * E)[: 2 * E]
+            matching.match(X11, X21, D11, D21)
+            g = self.graph
+            lc = c["local_opt"]
+            Twc = g["Twc"].clone()
+            if self.world > 1:
+                from mast3r_slam.global_opt import gauss_newton_sharded
+
+                gauss_newton_sharded("rays", Twc, g["Xs"], g["Cs"], None, g["ii"], g["jj"], g["idx_ii2jj"],
+                                     g["valid_match"], g["Q"], lc)
+            else:
+                be.gauss_newton_rays(Twc, g["Xs"], g["Cs"], g["ii"], g["jj"], g["idx_ii2jj"], g["valid_match"], g["Q"],
+                                     lc["sigma_ray"], lc["sigma_dist"], lc["C_conf"], lc["Q_conf"], lc["max_iters"],
+                                     lc["delta_norm"])
+            pts, conf, org = self.tsdf_pts, self.tsdf_conf, self.tsdf_org
+            if self.world > 1:
+                import torch.distributed as dist
+
+                gp = [torch.empty_like(pts) for _ in range(self.world)]
+                gc = [torch.empty_like(conf) for _ in range(self.world)]
+                go = [torch.empty_like(org) for _ in range(self.world)]
+                dist.all_gather(gp, pts); dist.all_gather(gc, conf); dist.all_gather(go, org)
+                for r in range(self.world):
+                    self.vol.integrate(gp[r], gc[r], go[r], return_fused=False)
+            else:
+                self.vol.integrate(pts, conf, org, return_fused=False)
+            self.tsdf_opt.refine_pose(Sim3(self.tsdf_pose), self.tsdf_cam_pts, self.tsdf_cam_conf, iterations=3)
+
+    def gflop_per_step_avg(self):
+        a = self.args
+        return self.flop_scale * GF_TRACK + GF_EDGE * a.edges_per_kf / a.kf_every
+
+
+def cpu_baseline(args):
+    """The oracle (kind = "port") timed on the host cores for a BOUNDED sample of the same workload:
+    one tracked frame (torch-CPU fp32 network restatement + C matching + numpy tracking GN) plus one
+    keyframe's backend with ONE symmetric edge direction of network (scaled to --edges-per-kf), one GN
+    iteration of the C restatement on a 4-keyframe graph (scaled) and the C TSDF on 40 000 points."""
+    import oracle
+    from oracle import mast3r_ref as R, matching_py, tracker_py
+    from mast3r_slam import synthetic
+    from mast3r_slam.config import config
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = R.Mast3rConfig()
+    sd = R.init_state_dict(cfg, seed=0)
+    img = torch.from_numpy(synthetic.render_rgb(synthetic.camera_pose(0), H, W))[None]
+    t0 = time.perf_counter()
+    with torch.inference_mode():
+        f1, p1 = R.encode_image(sd, cfg, img)
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        d1, d2 = R.decoder(sd, cfg, f1, p1, f1, p1)
+        t_dec = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        R.downstream_head(sd, cfg, 1, d1, H, W)
+        t_head = time.perf_counter() - t0
+    t_net_frame = t_enc + t_dec + 2 * t_head
+    t_net_edge = 2 * (t_dec + 2 * t_head)
+    del sd
+    pr = synthetic.make_pair(3, 0, h=H, w=W, seed=0)
+    t0 = time.perf_counter()
+    rays, pts, p0 = matching_py.prep_for_iter_proj(pr["X11"][None], pr["X21"][None])
+    mc = config["matching"]
+    p, conv = oracle.iter_proj(rays, pts, p0, mc["max_iter"], mc["lambda_init"], mc["convergence_thresh"])
+    p1i, v = matching_py.occlusion_and_trunc(pr["X11"][None], pr["X21"][None], p, conv, mc["dist_thresh"])
+    p1i = oracle.refine_matches(pr["D11"][None].astype(np.float16), pr["D21"].reshape(1, H * W, -1).astype(np.float16),
+                                p1i, mc["radius"], mc["dilation_max"])
+    t_match = time.perf_counter() - t0
+    idx = matching_py.pixel_to_lin(p1i, W)[0]
+    Tk = synthetic.camera_pose(0)
+    Xk = synthetic.render_pointmap(Tk, H, W).reshape(-1, 3).astype(np.float32)
+    t0 = time.perf_counter()
+    tracker_py.track(False, pr["X11"].reshape(-1, 3)[idx], Xk, synthetic.camera_pose(3).astype(np.float32),
+                     Tk.astype(np.float32), np.sqrt(pr["Q11"] * pr["Q21"]).reshape(-1), v[0], dict(config["tracking"]))
+    t_track = time.perf_counter() - t0
+    g = synthetic.make_graph(n_kf=4, h=H, w=W, seed=11, stride=4, extra_edges=1, pose_noise=0.01)
+    lc = config["local_opt"]
+    t0 = time.perf_counter()
+    oracle.gauss_newton("rays", g["Twc"], g["Xs"], g["Cs"], None, g["ii"], g["jj"], g["idx_ii2jj"], g["valid_match"],
+                        g["Q"], lc["sigma_ray"], lc["sigma_dist"], lc["C_conf"], lc["Q_conf"], 1, lc["delta_norm"])
+    e_small = len(g["ii"])
+    t_gn_edge_iter = (time.perf_counter() - t0) / e_small          # per directed edge per iteration (8 OpenMP threads)
+    n_edges_bench = 2 * ((args.graph_kfs - 1) + 2 * (args.graph_kfs - 2))
+    t_gn = t_gn_edge_iter * n_edges_bench * lc["max_iters"]
+    Xw = synthetic.sim3_act(Tk, Xk.astype(np.float64))
+    sel = np.random.default_rng(0).permutation(H * W)[:40000]
+    vol = oracle.TSDFVolume(0.03, 0.12)
+    t0 = time.perf_counter()
+    vol.integrate(Xw[sel].astype(np.float32), np.full(40000, 2.0), Tk[:3].astype(np.float32))
+    t_tsdf = time.perf_counter() - t0
+    per_frame = t_net_frame + t_match + t_track
+    per_kf = args.edges_per_kf * t_net_edge + 2 * args.edges_per_kf * t_match + t_gn + t_tsdf
+    sec_per_frame = per_frame + per_kf / args.kf_every
+    return dict(value=1.0 / sec_per_frame, unit="frames/s", cores=cores, kind="port",
+                sample=("1 tracked frame (torch-CPU fp32 network %.1fs, C matching %.2fs, numpy tracking GN %.2fs) + "
+                        "1 keyframe backend extrapolated from 1 decoder+heads pass, 1 GN iteration on %d edges, "
+                        "40k-point TSDF %.2fs" % (t_net_frame, t_match, t_track, e_small, t_tsdf)))
+
+
+def main():
+    args = parse()
+    rank, world, dev = dist_setup(args)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    import mslam_hip
+
+    mslam_hip.check(mslam_hip.lib().mslam_device_check(), "device_check")
+    pipe = Pipeline(args, rank, world, dev)
+    for f in range(args.warmup):
+        pipe.step(f)
+    barrier(world)
+    pipe.timing = True
+    pipe._pending = []
+    t0 = time.perf_counter()
+    for f in range(args.steps):
+        pipe.step(f)
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    net_ms = sum(a.elapsed_time(b) for a, b in pipe._pending)
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        fps = args.steps * world / elapsed
+        kf_steps = len([f for f in range(args.steps) if f % args.kf_every == 0])
+        gflop_total = args.steps * pipe.flop_scale * GF_TRACK + kf_steps * args.edges_per_kf * GF_EDGE
+        achieved = gflop_total / max(net_ms, 1e-9)  # GFLOP / ms = TFLOP/s
+        out = {
+            "metric": "SLAM frames/sec (infer+match+TSDF+GN) @512x384", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "synthetic 512x384 RGB-D stream, tracked frame every step + keyframe backend "
+                                   f"every {args.kf_every} frames ({args.edges_per_kf} symmetric edges, "
+                                   f"{args.graph_kfs * world}-keyframe GN graph, 40k-point TSDF fuse)",
+                       "weights": "random-init ViT-L/12+12 MASt3R architecture (no checkpoint offline)",
+                       "parallelism": f"streams x{world}, GN edges + TSDF voxels sharded"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "kernel": "gemm_bf16_kernel (network stage: algorithmic GFLOP / event-timed stage ms)",
+                         "network_ms_per_step": net_ms / args.steps},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -241,6 +241,27 @@ int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, const float* 
                      int max_iters, float rel_error, float delta_norm, void* status_out, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Building blocks of the MASt3R forward, exported for kernel-level parity tests and roofline
+ * measurement (they have no counterpart in the reference's API: it calls cuBLAS/cuDNN through
+ * torch, blocks.py:88-109, dpt_block.py:33-68).
+ * ------------------------------------------------------------------------------------------ */
+/* out[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ residual f32[M,N]); A, W bf16; act 0 none, 1 GELU(erf),
+ * 2 ReLU; out f32 or bf16.  K % 8 == 0. */
+int mslam_gemm_bf16(const void* A, const void* W, const float* bias, const void* residual_f32, void* out,
+                    int M, int N, int K, int act, int out_is_bf16, void* stream);
+/* NHWC bf16 conv (ks 1|3, stride 1|2, pad ks/2), W bf16 [Cout, ks*ks*Cin] tap-major; optional ReLU on
+ * the input, act on the output, bf16 residual added after act. */
+int mslam_conv2d_nhwc_bf16(const void* in, const void* W, const float* bias, const void* residual_bf16,
+                           void* out_bf16, int B, int H, int Wd, int Cin, int Cout, int ks, int stride,
+                           int relu_in, int act, void* stream);
+/* O[B,Nq,H*64] = softmax(Q K^T) V ; Q,K bf16 [B,H,N,64] (Q pre-scaled by 1/8), VT bf16 [B,H,64,Nk]. */
+int mslam_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int batch, int heads,
+                         int nq, int nk, void* stream);
+/* torch.nn.LayerNorm over the last dim (D <= 2048): x f32[rows,D] -> bf16 and/or f32 outputs. */
+int mslam_layernorm_f32(const float* x, const float* w, const float* b, void* out_bf16, float* out_f32,
+                        int rows, int D, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@
 // softmax and the whole post-processing are fp32.  Layout: tokens row-major [B*N, C] (== NHWC of the
 // 24x32 token grid), DPT feature maps NHWC bf16.  The 1x1 out_conv of each fusion block is applied
 // BEFORE the bilinear x2 upsample (both are linear and commute; 4x fewer FLOPs).
+#include <stdlib.h>
 #include <vector>
 #include "common.h"
 #include "gemm.h"
@@ -235,11 +236,12 @@ struct PtrFeed {
 
 // bump allocator over the caller's workspace; in dry mode only measures
 struct Arena {
-  char* base; size_t off = 0, cap; bool dry;
+  char* base; size_t off = 0, cap; bool dry; bool overflow = false;
   template <typename T> T* get(size_t n) {
     const size_t bytes = (n * sizeof(T) + 255) / 256 * 256;
     T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
     off += bytes;
+    if (!dry && off > cap) { overflow = true; return reinterpret_cast<T*>(base); }
     return p;
   }
 };
@@ -253,9 +255,20 @@ struct Ctx {
   void fail(int r) { if (rc == MSLAM_OK) rc = r; }
 };
 
+// MSLAM_DEBUG=1: synchronise after every launch and name it on stderr (fault localisation only)
+static void dbg(Ctx& c, const char* what, int a = 0, int b = 0, int d = 0) {
+  static const bool on = getenv("MSLAM_DEBUG") != nullptr;
+  if (!on || c.dry()) return;
+  fprintf(stderr, "[mslam] %s %d %d %d ...", what, a, b, d);
+  fflush(stderr);
+  hipError_t e = hipStreamSynchronize(c.s);
+  fprintf(stderr, " %s\n", hipGetErrorString(e));
+}
+
 static void run_gemm(Ctx& c, GemmArgs& g) {
   if (c.dry() || c.rc) return;
   c.fail(launch_gemm(g, c.s));
+  dbg(c, g.epi == EPI_ATTN ? "gemm_attn" : (g.a_conv ? "gemm_conv" : "gemm"), g.M, g.N, g.K);
 }
 
 static GemmArgs dense_args(const bf16* A, int M, const Lin& l) {
@@ -269,11 +282,13 @@ static void layernorm(Ctx& c, const float* x, const Norm& n, int rows, bf16* out
   if (c.dry() || c.rc) return;
   hipLaunchKernelGGL(layernorm_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, c.s, x, n.w, n.b, out_bf, out_f, rows,
                      n.d, 1e-6f);
+  dbg(c, "layernorm", rows, n.d);
 }
 
 static void cast_bf16(Ctx& c, const float* x, bf16* y, size_t n) {
   if (c.dry() || c.rc) return;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, c.s, x, y, n);
+  dbg(c, "cast", (int)n);
 }
 
 struct AttnBufs { bf16 *q, *k, *vt, *o; };
@@ -290,6 +305,7 @@ static void attn_project(Ctx& c, const bf16* A, int M, const Lin& l, int sec_bas
 static void attention(Ctx& c, const AttnBufs& ab, int B, int heads, int nq, int nk) {
   if (c.dry() || c.rc) return;
   c.fail(launch_attention(ab.q, ab.k, ab.vt, ab.o, B, heads, nq, nk, c.s));
+  dbg(c, "attention", B * heads, nq, nk);
 }
 
 // x (f32 residual stream, [M,D]) += Linear(A) (+bias)
@@ -341,6 +357,7 @@ static void encode(Ctx& c, const float* img, int B, int H, int W, float* feat_ou
     const size_t total = (size_t)M * KP;
     hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, img, patches, B, H, W,
                        m.P);
+    dbg(c, "patchify", B, H, W);
   }
   linear_f32(c, patches, M, m.pe, x);
   for (int i = 0; i < m.enc_depth; i++) {
@@ -391,6 +408,7 @@ static bf16* upsample2x(Ctx& c, const bf16* in, int B, int H, int W, int C) {
   if (!c.dry() && !c.rc) {
     const size_t total = (size_t)B * 4 * H * W * (C / 8);
     hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, in, out, B, H, W, C);
+    dbg(c, "upsample2x", H, W, C);
   }
   return out;
 }
@@ -404,7 +422,8 @@ static bf16* rcu(Ctx& c, const bf16* x, int B, int H, int W, int C, const Rcu& r
 // FeatureFusionBlock_custom (dpt_block.py:144-218): returns the x2-upsampled, out_conv'ed map
 static bf16* fusion(Ctx& c, const Fusion& f, const bf16* path, const bf16* layer, int B, int H, int W, int C) {
   const bf16* s = path;
-  if (layer) s = rcu(c, layer, B, H, W, C, f.r1, path);  // path + resConfUnit1(layer)
+  // NB: test the model flag, not the pointer - in the dry (sizing) pass every arena pointer is null
+  if (f.has_r1) s = rcu(c, layer, B, H, W, C, f.r1, path);  // path + resConfUnit1(layer)
   bf16* r = rcu(c, s, B, H, W, C, f.r2, nullptr);
   bf16* o = conv(c, r, B, H, W, C, f.out, 1, 1, 0, ACT_NONE, nullptr, nullptr);
   return upsample2x(c, o, B, H, W, C);
@@ -453,6 +472,7 @@ static void run_head(Ctx& c, const Head& hd, const bf16* const toks[4], int B, i
     const size_t total = (size_t)M * idim;
     hipLaunchKernelGGL(concat2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.s, toks[0], m.E, toks[3],
                        m.Dd, cat, (size_t)M);
+    dbg(c, "concat2", M);
   }
   linear_bf16(c, cat, M, hd.fc1, hid, ACT_GELU);
   linear_f32(c, hid, M, hd.fc2, lf);
@@ -460,6 +480,7 @@ static void run_head(Ctx& c, const Head& hd, const bf16* const toks[4], int B, i
     const size_t npix = (size_t)B * H * W;
     hipLaunchKernelGGL(head_post_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c.s, h2, hd.h2.out, hd.h4w,
                        hd.h4b, lf, hd.fc2.out, m.desc_dim, m.P, B, H, W, out.X, out.C, out.D, out.Q);
+    dbg(c, "head_post", B, H, W);
   }
 }
 
@@ -650,6 +671,7 @@ extern "C" int mslam_mast3r_encode(void* handle, const float* img, int batch, in
   MSLAM_REQUIRE(workspace_bytes >= mslam_mast3r_workspace_bytes(handle, batch, H, W), "mast3r_encode: workspace too small");
   Ctx c{m, Arena{(char*)workspace, 0, workspace_bytes, false}, (hipStream_t)stream};
   encode(c, img, batch, H, W, feat_out);
+  MSLAM_REQUIRE(!c.ar.overflow, "mast3r_encode: workspace arena overflow (%zu > %zu)", c.ar.off, c.ar.cap);
   if (c.rc) return c.rc;
   return check_hip(hipGetLastError(), "mast3r_encode launch");
 }
@@ -666,6 +688,49 @@ extern "C" int mslam_mast3r_decode(void* handle, const float* feat1, const float
   Ctx c{m, Arena{(char*)workspace, 0, workspace_bytes, false}, (hipStream_t)stream};
   HeadOut out[2] = {{X1, C1, D1, Q1}, {X2, C2, D2, Q2}};
   decode(c, feat1, feat2, batch, H, W, out, dec_last1, dec_last2);
+  MSLAM_REQUIRE(!c.ar.overflow, "mast3r_decode: workspace arena overflow (%zu > %zu)", c.ar.off, c.ar.cap);
   if (c.rc) return c.rc;
   return check_hip(hipGetLastError(), "mast3r_decode launch");
+}
+
+// ---- kernel-level entry points (unit tests, roofline measurement) -------------------------------
+extern "C" int mslam_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* residual_f32, void* out,
+                               int M, int N, int K, int act, int out_is_bf16, void* stream) {
+  MSLAM_REQUIRE(A && Wt && out, "gemm_bf16: null pointer");
+  GemmArgs g = {};
+  g.A = (const bf16*)A; g.W = (const bf16*)Wt; g.M = M; g.N = N; g.K = K; g.lda = K; g.bias = bias; g.act = act;
+  g.out = out; g.out_kind = out_is_bf16 ? KIND_BF16 : KIND_F32; g.ldc = N; g.ldr1 = N; g.ldr2 = N;
+  if (residual_f32) { g.res1 = residual_f32; g.res1_kind = KIND_F32; }
+  return launch_gemm(g, (hipStream_t)stream);
+}
+
+// NHWC bf16 convolution (ks in {1,3}, stride in {1,2}, zero pad ks/2) as implicit GEMM; W [Cout, ks*ks*Cin]
+extern "C" int mslam_conv2d_nhwc_bf16(const void* in, const void* Wt, const float* bias, const void* residual_bf16,
+                                      void* out_bf16, int B, int H, int Wd, int Cin, int Cout, int ks, int stride,
+                                      int relu_in, int act, void* stream) {
+  MSLAM_REQUIRE(in && Wt && out_bf16, "conv2d: null pointer");
+  MSLAM_REQUIRE((ks == 1 || ks == 3) && (stride == 1 || stride == 2), "conv2d: unsupported ks/stride");
+  Lin l; l.W = (const bf16*)Wt; l.b = bias; l.out = Cout; l.in = ks * ks * Cin;
+  GemmArgs g = conv_args((const bf16*)in, B, H, Wd, Cin, l, ks, stride);
+  g.out = out_bf16; g.a_relu = relu_in; g.act = act;
+  if (residual_bf16) { g.res1 = residual_bf16; g.res1_kind = KIND_BF16; }
+  return launch_gemm(g, (hipStream_t)stream);
+}
+
+// softmax(Q K^T) V with Q,K [B,H,N,64] (q pre-scaled), V^T [B,H,64,Nk] -> O [B,Nq,H*64], all bf16
+extern "C" int mslam_attention_bf16(const void* Q, const void* K, const void* VT, void* O, int batch, int heads,
+                                    int nq, int nk, void* stream) {
+  MSLAM_REQUIRE(Q && K && VT && O, "attention: null pointer");
+  return launch_attention((const bf16*)Q, (const bf16*)K, (const bf16*)VT, (bf16*)O, batch, heads, nq, nk,
+                          (hipStream_t)stream);
+}
+
+extern "C" int mslam_layernorm_f32(const float* x, const float* w, const float* b, void* out_bf16, float* out_f32,
+                                   int rows, int D, float eps, void* stream) {
+  MSLAM_REQUIRE(x && w && b && (out_bf16 || out_f32), "layernorm: null pointer");
+  MSLAM_REQUIRE(D <= 2048 && rows > 0, "layernorm: D=%d must be <= 2048", D);
+  hipLaunchKernelGGL(layernorm_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b,
+                     (bf16*)out_bf16, out_f32, rows, D, eps);
+  MSLAM_LAUNCH_CHECK("layernorm");
+  return MSLAM_OK;
 }

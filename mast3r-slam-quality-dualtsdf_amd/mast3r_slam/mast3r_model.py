@@ -224,3 +224,64 @@ def load_mast3r_state_dict(path):
             f"{path}: MASt3R checkpoint not found (the reference downloads it, README.md:63-65; no network here)")
     ckpt = torch.load(path, map_location="cpu", weights_only=True)
     return ckpt["model"] if "model" in ckpt else ckpt
+
+
+def random_state_dict(cfg: Mast3rConfig, seed=0):
+    """Seeded random weights with the upstream key layout (no checkpoint is available offline; the
+    bench states this in its `data`/`config` fields).  Xavier-style scales keep activations O(1)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def lin(name, o, i, bias=True):
+        sd[name + ".weight"] = (torch.rand(o, i, generator=g) * 2 - 1) * (6.0 / (i + o)) ** 0.5
+        if bias:
+            sd[name + ".bias"] = (torch.rand(o, generator=g) * 2 - 1) * 0.02
+
+    def ln(name, d):
+        sd[name + ".weight"] = 1 + 0.1 * (torch.rand(d, generator=g) * 2 - 1)
+        sd[name + ".bias"] = 0.05 * (torch.rand(d, generator=g) * 2 - 1)
+
+    def conv(name, o, i, k, bias=True, transpose=False):
+        shape = (i, o, k, k) if transpose else (o, i, k, k)
+        sd[name + ".weight"] = (torch.rand(*shape, generator=g) * 2 - 1) * (3.0 / (i * k * k)) ** 0.5
+        if bias:
+            sd[name + ".bias"] = (torch.rand(o, generator=g) * 2 - 1) * 0.02
+
+    E, D, P = cfg.enc_dim, cfg.dec_dim, cfg.patch
+    conv("patch_embed.proj", E, 3, P)
+    for i in range(cfg.enc_depth):
+        p = f"enc_blocks.{i}"
+        ln(p + ".norm1", E); lin(p + ".attn.qkv", 3 * E, E); lin(p + ".attn.proj", E, E)
+        ln(p + ".norm2", E); lin(p + ".mlp.fc1", 4 * E, E); lin(p + ".mlp.fc2", E, 4 * E)
+    ln("enc_norm", E)
+    lin("decoder_embed", D, E)
+    for blocks in ("dec_blocks", "dec_blocks2"):
+        for i in range(cfg.dec_depth):
+            p = f"{blocks}.{i}"
+            ln(p + ".norm1", D); lin(p + ".attn.qkv", 3 * D, D); lin(p + ".attn.proj", D, D)
+            ln(p + ".norm2", D); ln(p + ".norm_y", D)
+            for q in ("projq", "projk", "projv", "proj"):
+                lin(f"{p}.cross_attn.{q}", D, D)
+            ln(p + ".norm3", D); lin(p + ".mlp.fc1", 4 * D, D); lin(p + ".mlp.fc2", D, 4 * D)
+    ln("dec_norm", D)
+    fd, dims = cfg.feature_dim, [96, 192, 384, 768]
+    for h in (1, 2):
+        p = f"downstream_head{h}.dpt"
+        a = p + ".act_postprocess"
+        conv(a + ".0.0", dims[0], E, 1); conv(a + ".0.1", dims[0], dims[0], 4, transpose=True)
+        conv(a + ".1.0", dims[1], D, 1); conv(a + ".1.1", dims[1], dims[1], 2, transpose=True)
+        conv(a + ".2.0", dims[2], D, 1)
+        conv(a + ".3.0", dims[3], D, 1); conv(a + ".3.1", dims[3], dims[3], 3)
+        for i, d in enumerate(dims):
+            conv(f"{p}.scratch.layer_rn.{i}", fd, d, 3, bias=False)
+        for r in (1, 2, 3, 4):
+            q = f"{p}.scratch.refinenet{r}"
+            conv(q + ".out_conv", fd, fd, 1)
+            for u in (1, 2):
+                conv(f"{q}.resConfUnit{u}.conv1", fd, fd, 3); conv(f"{q}.resConfUnit{u}.conv2", fd, fd, 3)
+        conv(p + ".head.0", fd // 2, fd, 3); conv(p + ".head.2", fd // 2, fd // 2, 3); conv(p + ".head.4", 4, fd // 2, 1)
+        sd[p + ".head.4.weight"] *= 0.1   # keep xyz / conf logits O(1) (expm1 / exp follow)
+        idim = E + D
+        lin(f"downstream_head{h}.head_local_features.fc1", 4 * idim, idim)
+        lin(f"downstream_head{h}.head_local_features.fc2", (cfg.desc_dim + 1) * P * P, 4 * idim)
+    return sd
