@@ -205,6 +205,9 @@ struct Mast3rModel {
   float* rope_sin = nullptr;
   int rope_len = 0;
   int hooks[4];
+  hipStream_t side_stream = nullptr;   // second queue: decoder side 2 / head 2 run beside side 1 / head 1
+  std::vector<hipEvent_t> events;      // fork/join events, cycled
+  mutable size_t ev_next = 0;
 };
 
 struct PtrFeed {
@@ -502,43 +505,71 @@ static void dec_block(Ctx& c, const DecBlock& b, float* x, const bf16* yn, int B
 }
 
 // feat1/feat2 f32 [B*N, E]; outputs for both sides; dec_last (optional) f32 [2][B*N, Dd]
+// fork/join between the caller's stream and the model's side stream (no-ops in the sizing pass)
+static void stream_wait(Ctx& c, hipStream_t waiter, hipStream_t on) {
+  if (c.dry() || c.rc) return;
+  const Mast3rModel& m = *c.m;
+  hipEvent_t ev = m.events[m.ev_next++ % m.events.size()];
+  c.fail(check_hip(hipEventRecord(ev, on), "hipEventRecord"));
+  c.fail(check_hip(hipStreamWaitEvent(waiter, ev, 0), "hipStreamWaitEvent"));
+}
+
+// feat1/feat2 f32 [B*N, E]; outputs for both sides; dec_last (optional) f32 [2][B*N, Dd].
+// The two sides of a decoder layer are independent (both read the PREVIOUS layer's outputs,
+// dust3r/model.py:178-183) and at one image per side neither fills 256 CUs, so side 1 runs on the
+// caller's stream and side 2 on the model's side stream, joined once per layer; the two heads likewise.
 static void decode(Ctx& c, const float* feat1, const float* feat2, int B, int H, int W, const HeadOut out[2],
                    float* dec_last1, float* dec_last2) {
   const Mast3rModel& m = *c.m;
   const int nh = H / m.P, nw = W / m.P, N = nh * nw, M = B * N;
   const float* feat[2] = {feat1, feat2};
+  float* dec_last[2] = {dec_last1, dec_last2};
+  hipStream_t sA = c.s, sB = (c.dry() || !m.side_stream) ? c.s : m.side_stream;
+  hipStream_t st[2] = {sA, sB};
   bf16* fb[2];
   float* x[2];
   bf16* yn[2];
   bf16* tok[2][4];
+  BlockScratch bs[2];
   for (int s = 0; s < 2; s++) {
     fb[s] = c.ar.get<bf16>((size_t)M * m.E);
     x[s] = c.ar.get<float>((size_t)M * m.Dd);
     yn[s] = c.ar.get<bf16>((size_t)M * m.Dd);
     for (int k = 1; k < 4; k++) tok[s][k] = c.ar.get<bf16>((size_t)M * m.Dd);
     tok[s][0] = fb[s];
+    bs[s] = block_scratch(c, M, m.Dd);
+  }
+  if (sB != sA) stream_wait(c, sB, sA);  // fork: side stream starts after everything already queued
+  for (int s = 0; s < 2; s++) {
+    c.s = st[s];
     cast_bf16(c, feat[s], fb[s], (size_t)M * m.E);
     linear_f32(c, fb[s], M, m.dec_embed, x[s]);
   }
-  BlockScratch bs = block_scratch(c, M, m.Dd);
   for (int l = 0; l < m.dec_depth; l++) {
-    // both sides read the PREVIOUS layer's output of the other side (model.py:178-183): normalise
-    // the memories first, then update each residual stream in place
-    layernorm(c, x[1], m.dec[0][l].ny, M, yn[0], nullptr);  // memory for side 1 = norm_y(f2)
-    layernorm(c, x[0], m.dec[1][l].ny, M, yn[1], nullptr);  // memory for side 2 = norm_y(f1)
-    dec_block(c, m.dec[0][l], x[0], yn[0], B, N, N, nw, nw, bs);
-    dec_block(c, m.dec[1][l], x[1], yn[1], B, N, N, nw, nw, bs);
-    for (int k = 1; k < 3; k++)
-      if (l + 1 == m.hooks[k])
-        for (int s = 0; s < 2; s++) cast_bf16(c, x[s], tok[s][k], (size_t)M * m.Dd);
+    c.s = sA;
+    if (sB != sA) stream_wait(c, sA, sB);                     // x[1] of the previous layer is final
+    layernorm(c, x[1], m.dec[0][l].ny, M, yn[0], nullptr);    // memory for side 1 = norm_y(f2)
+    layernorm(c, x[0], m.dec[1][l].ny, M, yn[1], nullptr);    // memory for side 2 = norm_y(f1)
+    if (sB != sA) stream_wait(c, sB, sA);                     // memories ready; x[0] final for side 2's reads
+    for (int s = 0; s < 2; s++) {
+      c.s = st[s];
+      dec_block(c, m.dec[s][l], x[s], yn[s], B, N, N, nw, nw, bs[s]);
+      for (int k = 1; k < 3; k++)
+        if (l + 1 == m.hooks[k]) cast_bf16(c, x[s], tok[s][k], (size_t)M * m.Dd);
+    }
   }
-  layernorm(c, x[0], m.dec_norm, M, tok[0][3], dec_last1);
-  layernorm(c, x[1], m.dec_norm, M, tok[1][3], dec_last2);
   const size_t mark = c.ar.off;
+  size_t end = mark;
   for (int s = 0; s < 2; s++) {
-    c.ar.off = mark;  // the two heads reuse the same scratch region (stream-ordered)
+    c.s = st[s];
+    layernorm(c, x[s], m.dec_norm, M, tok[s][3], dec_last[s]);
+    // each head gets its own scratch region when the two run concurrently
+    c.ar.off = (sB != sA || c.dry()) ? end : mark;
     run_head(c, m.head[s], tok[s], B, H, W, out[s]);
+    end = c.ar.off;
   }
+  c.s = sA;
+  if (sB != sA) stream_wait(c, sA, sB);  // join
 }
 
 }  // namespace mslam
@@ -625,6 +656,14 @@ extern "C" int mslam_mast3r_create(void** handle_out, const int* cfg9, void* con
   if (!rc) rc = check_hip(hipMemcpyAsync(m->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream), "rope copy");
   if (!rc) rc = check_hip(hipMemcpyAsync(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream), "rope copy");
   if (!rc) rc = check_hip(hipStreamSynchronize((hipStream_t)stream), "rope sync");
+  if (!rc && !getenv("MSLAM_SINGLE_STREAM")) {
+    rc = check_hip(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking), "side stream");
+    for (int k = 0; k < 64 && !rc; k++) {
+      hipEvent_t ev;
+      rc = check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "event");
+      if (!rc) m->events.push_back(ev);
+    }
+  }
   if (rc) { delete m; return rc; }
   *handle_out = m;
   return MSLAM_OK;
@@ -635,6 +674,8 @@ extern "C" int mslam_mast3r_destroy(void* handle) {
   if (!m) return MSLAM_OK;
   if (m->rope_cos) (void)hipFree(m->rope_cos);
   if (m->rope_sin) (void)hipFree(m->rope_sin);
+  for (hipEvent_t ev : m->events) (void)hipEventDestroy(ev);
+  if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
   delete m;
   return MSLAM_OK;
 }
