@@ -215,21 +215,35 @@ def cpu_baseline(args):
     from mast3r_slam import synthetic
     from mast3r_slam.config import config
 
+    def note(msg):
+        print(f"[cpu_baseline] {msg}", file=sys.stderr, flush=True)
+
     cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = max(1, min(cores, 16))   # a 1-GPU box grants a 16-core share; more threads only oversubscribe it
+    os.environ["OMP_NUM_THREADS"] = str(cores)   # C oracle (OpenMP), read when liboracle.so is first loaded
     torch.set_num_threads(cores)
+    note(f"{cores} cores; building random fp32 weights")
     cfg = R.Mast3rConfig()
     sd = R.init_state_dict(cfg, seed=0)
     img = torch.from_numpy(synthetic.render_rgb(synthetic.camera_pose(0), H, W))[None]
+    note("network (torch CPU fp32): encoder")
     t0 = time.perf_counter()
     with torch.inference_mode():
         f1, p1 = R.encode_image(sd, cfg, img)
         t_enc = time.perf_counter() - t0
+        note(f"encoder {t_enc:.1f}s; decoder")
         t0 = time.perf_counter()
         d1, d2 = R.decoder(sd, cfg, f1, p1, f1, p1)
         t_dec = time.perf_counter() - t0
+        note(f"decoder {t_dec:.1f}s; head")
         t0 = time.perf_counter()
         R.downstream_head(sd, cfg, 1, d1, H, W)
         t_head = time.perf_counter() - t0
+        note(f"head {t_head:.1f}s; matching")
     t_net_frame = t_enc + t_dec + 2 * t_head
     t_net_edge = 2 * (t_dec + 2 * t_head)
     del sd
@@ -242,6 +256,7 @@ def cpu_baseline(args):
     p1i = oracle.refine_matches(pr["D11"][None].astype(np.float16), pr["D21"].reshape(1, H * W, -1).astype(np.float16),
                                 p1i, mc["radius"], mc["dilation_max"])
     t_match = time.perf_counter() - t0
+    note(f"matching {t_match:.2f}s; tracking GN")
     idx = matching_py.pixel_to_lin(p1i, W)[0]
     Tk = synthetic.camera_pose(0)
     Xk = synthetic.render_pointmap(Tk, H, W).reshape(-1, 3).astype(np.float32)
@@ -249,6 +264,7 @@ def cpu_baseline(args):
     tracker_py.track(False, pr["X11"].reshape(-1, 3)[idx], Xk, synthetic.camera_pose(3).astype(np.float32),
                      Tk.astype(np.float32), np.sqrt(pr["Q11"] * pr["Q21"]).reshape(-1), v[0], dict(config["tracking"]))
     t_track = time.perf_counter() - t0
+    note(f"tracking GN {t_track:.2f}s; backend GN")
     g = synthetic.make_graph(n_kf=4, h=H, w=W, seed=11, stride=4, extra_edges=1, pose_noise=0.01)
     lc = config["local_opt"]
     t0 = time.perf_counter()
@@ -258,6 +274,7 @@ def cpu_baseline(args):
     t_gn_edge_iter = (time.perf_counter() - t0) / e_small          # per directed edge per iteration (8 OpenMP threads)
     n_edges_bench = 2 * ((args.graph_kfs - 1) + 2 * (args.graph_kfs - 2))
     t_gn = t_gn_edge_iter * n_edges_bench * lc["max_iters"]
+    note(f"GN {t_gn_edge_iter:.3f}s per edge-iteration; TSDF")
     Xw = synthetic.sim3_act(Tk, Xk.astype(np.float64))
     sel = np.random.default_rng(0).permutation(H * W)[:40000]
     vol = oracle.TSDFVolume(0.03, 0.12)

@@ -25,9 +25,12 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#if defined(__F16C__)
+#include <immintrin.h>
+#endif
 
 /* ---------- IEEE binary16 <-> binary32, software, round-to-nearest-even ---------- */
-static inline float half_to_float(uint16_t h) {
+static inline float half_to_float_sw(uint16_t h) {
   uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
   uint32_t exp = (h >> 10) & 0x1Fu;
   uint32_t man = h & 0x3FFu;
@@ -51,7 +54,7 @@ static inline float half_to_float(uint16_t h) {
   return out;
 }
 
-static inline uint16_t float_to_half(float x) {
+static inline uint16_t float_to_half_sw(float x) {
   uint32_t f;
   memcpy(&f, &x, 4);
   uint32_t sign = (f >> 16) & 0x8000u;
@@ -78,6 +81,19 @@ static inline uint16_t float_to_half(float x) {
   if (rem > 0x1000u || (rem == 0x1000u && (hm & 1))) out++; /* carries into exponent correctly */
   return out;
 }
+
+#if defined(__F16C__)
+/* F16C conversions are IEEE round-to-nearest-even, bit-identical to the software routines above
+ * (tests/test_matching_oracle.py checks the software path exhaustively against numpy). */
+static inline float half_to_float(uint16_t h) { return _cvtsh_ss(h); }
+static inline uint16_t float_to_half(float x) { return _cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+#else
+static inline float half_to_float(uint16_t h) { return half_to_float_sw(h); }
+static inline uint16_t float_to_half(float x) { return float_to_half_sw(x); }
+#endif
+uint16_t oracle_float_to_half_sw(float x) { return float_to_half_sw(x); }
+float oracle_half_to_float_sw(uint16_t h) { return half_to_float_sw(h); }
+uint16_t oracle_float_to_half(float x) { return float_to_half(x); }
 
 /* half*half is exact in float (22-bit product), half+half in float then RNE to half is
  * correctly rounded (24 >= 2*11+2), so float arithmetic + one rounding == IEEE half ops. */
@@ -127,6 +143,7 @@ void oracle_iter_proj(const float* rays_img, const float* pts_3d_norm, const flo
                       float lambda_init, float cost_thresh) {
   for (int bi = 0; bi < b; bi++) {
     const float* img = rays_img + (size_t)bi * h * w * 9;
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++) {
       size_t o = (size_t)bi * n + i;
       const float* tgt = pts_3d_norm + o * 3;
@@ -195,6 +212,7 @@ void oracle_refine_matches(const uint16_t* D11, const uint16_t* D21, const int64
                            int dilation_max, int fused_fma) {
   for (int bi = 0; bi < b; bi++) {
     const uint16_t* img = D11 + (size_t)bi * h * w * fdim;
+#pragma omp parallel for schedule(dynamic, 256)
     for (int i = 0; i < n; i++) {
       size_t o = (size_t)bi * n + i;
       const uint16_t* d21 = D21 + o * fdim;
