@@ -262,6 +262,25 @@ int mslam_attention_bf16(const void* Q, const void* K, const void* VT, void* O, 
 int mslam_layernorm_f32(const float* x, const float* w, const float* b, void* out_bf16, float* out_f32,
                         int rows, int D, float eps, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Local dense-block TSDF (camera-side half of the "dual TSDF"): replaces the python loops of
+ * TSDFRefiner._build_tsdf_robust (mast3r_slam/tsdf_refine.py:837-940) and
+ * _extract_surface_safe + _sample_tsdf_trilinear (:942-1064).  Grid layout [nz,ny,nx] f32, dims
+ * (<= 64 per axis) computed by the caller as clamp(ceil(roi/voxel_size), max=max_grid_dim) (:844-846).
+ * build: X_world f32[n,3] = T_WC.act(X_canon), C f32[n], origin/xyz_min/xyz_max f32[3] (device);
+ * sequential float32 running-average semantics are preserved by per-voxel ordered replay.
+ * raycast: sel_pix i64[n_sel] = pixel indices to march (the reference draws <= 100 with randperm);
+ * surf f32[n_sel,3] <- surface point (or the original point), hit u8[n_sel].
+ * ------------------------------------------------------------------------------------------ */
+size_t mslam_tsdf_local_workspace_bytes(int n_points);
+int mslam_tsdf_local_build(const float* X_world, const float* C, const float* origin, const float* xyz_min,
+                           const float* xyz_max, int n_points, int nx, int ny, int nz, double voxel_size,
+                           double trunc, float min_confidence, float* tsdf, float* weights, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int mslam_tsdf_local_raycast(const float* tsdf, int nx, int ny, int nz, const float* xyz_min,
+                             const float* xyz_max, const float* X_original, const int64_t* sel_pix, int n_sel,
+                             int n_samples, float max_displacement, float* surf, uint8_t* hit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

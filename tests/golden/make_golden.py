@@ -243,6 +243,71 @@ def section_network():
 SECTIONS["network"] = section_network
 
 
+def section_tsdf_refine():
+    """Local dense-block TSDF of the dual-TSDF refiner: _build_tsdf_robust (tsdf_refine.py:837-940) and
+    _extract_surface_safe + _sample_tsdf_trilinear (:942-1064), by running the reference's
+    tsdf_refine.py (loaded by file path; its optional geometry import falls back, :21-29) with a
+    duck-typed Sim3 pose exposing .matrix() and .act()."""
+    import contextlib
+    import io
+
+    from mast3r_slam import synthetic
+
+    tr = load_by_path("ref_tsdf_refine", f"{REF}/mast3r_slam/tsdf_refine.py")
+    cfg = dict(enabled=True, window_size=5, voxel_size=0.02, trunc_dist=0.08, max_grid_dim=64, roi_size=0.4,
+               ray_samples=64, max_displacement=0.015, min_weight_threshold=0.01, confidence_boost=0.08,
+               confidence_max=1.3, min_hit_rate=0.05, max_rois_per_kf=3, min_confidence=0.2)
+
+    class Pose:
+        def __init__(self, T):
+            self.T = np.asarray(T, np.float64)
+
+        def matrix(self):
+            import scipy.spatial.transform as sst
+            M = np.eye(4, dtype=np.float32)
+            M[:3, :3] = (self.T[7] * sst.Rotation.from_quat(self.T[3:7]).as_matrix()).astype(np.float32)
+            M[:3, 3] = self.T[:3].astype(np.float32)
+            return torch.from_numpy(M)[None]
+
+        def act(self, X):
+            return torch.from_numpy(synthetic.sim3_act(self.T, X.numpy().astype(np.float64)).astype(np.float32))
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = tr.TSDFRefiner(dict(cfg), None, None, "cpu")
+    H, W = 48, 64
+    Tcam = synthetic.camera_pose(2)
+    X = synthetic.render_pointmap(Tcam, H, W).reshape(-1, 3)
+    rng = np.random.default_rng(4)
+    X = (X + rng.normal(0, 0.003, X.shape)).astype(np.float32)
+    C = rng.uniform(0.1, 1.2, H * W).astype(np.float32)
+    save = dict(X=X, C=C, H=H, W=W)
+    # case A: identity pose (camera frame == world frame: the only setting in which the reference's
+    # ray cast, done in camera coordinates, meets the world-frame grid);  case B: a small Sim3 pose
+    for name, T in (("A", np.array([0, 0, 0, 0, 0, 0, 1, 1.0])), ("B", np.array([0.05, -0.02, 0.03, 0.01, 0.02, -0.015, 0.9996, 1.02]))):
+        T[3:7] /= np.linalg.norm(T[3:7])
+        pose = Pose(T)
+        ys, xs = np.meshgrid(np.arange(16, 32), np.arange(24, 40), indexing="ij")   # one 16x16 patch
+        mask = np.zeros(H * W, bool)
+        mask[(ys * W + xs).reshape(-1)] = True
+        Xw = pose.act(torch.from_numpy(X)).numpy()
+        xyz_min = torch.from_numpy(Xw[mask].min(0) - 0.04)
+        xyz_max = torch.from_numpy(Xw[mask].max(0) + 0.04)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tsdf, weights = ref._build_tsdf_robust(torch.from_numpy(X), torch.from_numpy(C), None, xyz_min, xyz_max, H, W, pose)
+            torch.manual_seed(123)
+            perm = torch.randperm(int(mask.sum()))[:100]
+            torch.manual_seed(123)
+            X_ref, hits = ref._extract_surface_safe(tsdf, xyz_min, xyz_max, None, torch.from_numpy(mask), H, W, torch.from_numpy(X))
+        save.update({f"{name}_pose": T.astype(np.float32), f"{name}_mask": mask, f"{name}_xyz_min": xyz_min.numpy(),
+                     f"{name}_xyz_max": xyz_max.numpy(), f"{name}_tsdf": tsdf.numpy(), f"{name}_weights": weights.numpy(),
+                     f"{name}_perm": perm.numpy(), f"{name}_X_refined": X_ref.numpy(), f"{name}_hits": hits.numpy()})
+        print(name, "grid", tuple(tsdf.shape), "touched voxels", int((weights > 0).sum()), "hits", int(hits.sum()))
+    np.savez_compressed(os.path.join(HERE, "tsdf_refine.npz"), **save, **meta())
+
+
+SECTIONS["tsdf_refine"] = section_tsdf_refine
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s in todo:
