@@ -14,6 +14,22 @@ import torch
 import mslam_hip as _m
 
 
+_KEY_BIAS = 1 << 20
+
+
+def voxel_shard(keys, num_shards):
+    """Owner rank of integer voxel keys (n,3): host restatement of the device rule in
+    csrc/tsdf_global.hip (pack 3x21-bit biased key, murmur3 finaliser, bits 40.. mod num_shards).
+    Used by the multi-rank tests and by callers that route queries to the owning rank."""
+    k = np.asarray(keys, np.int64) + _KEY_BIAS
+    key = (k[:, 0].astype(np.uint64) << np.uint64(42)) | (k[:, 1].astype(np.uint64) << np.uint64(21)) | k[:, 2].astype(np.uint64)
+    with np.errstate(over="ignore"):
+        key ^= key >> np.uint64(33); key *= np.uint64(0xff51afd7ed558ccd)
+        key ^= key >> np.uint64(33); key *= np.uint64(0xc4ceb9fe1a85ec53)
+        key ^= key >> np.uint64(33)
+    return ((key >> np.uint64(40)) % np.uint64(num_shards)).astype(np.int64)
+
+
 class TSDFVolume:
     def __init__(self, voxel_size, truncation, max_weight=100.0, min_weight=1.0e-3, capacity=1 << 22,
                  device="cuda", shard_id=0, num_shards=1):
