@@ -133,6 +133,25 @@ class Pipeline:
         self.tsdf_cam_pts = t(synthetic.render_pointmap(Tk, H, W).reshape(-1, 3)[sel[:2000]].astype(np.float32))
         self.tsdf_cam_conf = t(rng.uniform(0.5, 3.0, 2000).astype(np.float32))
         self.tsdf_pose = t(Tk.astype(np.float32)).reshape(1, 8)
+        # local (camera-side) TSDF refine: max_rois_per_kf 32x32-pixel blocks of the newest keyframe
+        from lietorch_hip import Sim3
+        from mast3r_slam.frame import Frame, KeyframeStore
+        from mast3r_slam.tsdf_refine import PatchBlock, TSDFRefiner
+
+        Xc = (synthetic.render_pointmap(Tk, H, W).reshape(-1, 3) + rng.normal(0, 0.003, (H * W, 3))).astype(np.float32)
+        kf = Frame(0, self.frames[0], torch.tensor([[H, W]]), torch.tensor([[H, W]]), None,
+                   Sim3(t(Tk.astype(np.float32)).reshape(1, 8)), t(Xc), t(rng.uniform(0.3, 1.0, (H * W, 1)).astype(np.float32)))
+        kf.N = 1
+        store = KeyframeStore()
+        store.append(kf)
+        self.refiner = TSDFRefiner(dict(config["tsdf_refine"]), store, None, dev)
+        self.refine_C0 = kf.C.clone()
+        self.refine_blocks = []
+        for b in range(int(config["tsdf_refine"]["max_rois_per_kf"])):
+            y0, x0 = 64 + 96 * b, 96 + 128 * b
+            m = torch.zeros(H, W, dtype=torch.bool, device=dev)
+            m[y0:y0 + 32, x0:x0 + 32] = True
+            self.refine_blocks.append(PatchBlock(0, b, m.reshape(-1)))
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         self.net_ms = 0.0
         self.net_calls = 0
@@ -199,6 +218,9 @@ class Pipeline:
             else:
                 self.vol.integrate(pts, conf, org, return_fused=False)
             self.tsdf_opt.refine_pose(Sim3(self.tsdf_pose), self.tsdf_cam_pts, self.tsdf_cam_conf, iterations=3)
+            self.refiner.keyframes[0].C.copy_(self.refine_C0)
+            for blk in self.refine_blocks:
+                self.refiner.refine_block(blk)
 
     def gflop_per_step_avg(self):
         a = self.args
