@@ -24,7 +24,7 @@ struct GemmArgs {
   int M, N, K;
   int lda;
   // implicit-conv view of A (a_conv != 0): NHWC input [B, cH, cW, cC], k = tap*cC + c
-  int a_conv, cH, cW, cC, cKs, cStride, cPad, cHo, cWo;
+  int a_conv, cB, cH, cW, cC, cKs, cStride, cPad, cHo, cWo;
   int a_relu;  // ReLU applied to A on load (pre-activation of the DPT residual units)
   // epilogue
   const float* bias;

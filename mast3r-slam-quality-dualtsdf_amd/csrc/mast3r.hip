@@ -66,6 +66,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
   }
 }
 
+// Vectorised form for D == NV * 256 (the 1024 / 768 wide streams of the real model): one wave per row,
+// 16-byte loads, gamma/beta fetched before the reductions so their latency overlaps them.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, bf16* __restrict__ out_bf,
+                                                            float* __restrict__ out_f, int rows, float eps) {
+  constexpr int D = NV * 256;
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  float4 v[NV], wv[NV], bv[NV];
+#pragma unroll
+  for (int c = 0; c < NV; c++) v[c] = xr[lane + 64 * c];
+#pragma unroll
+  for (int c = 0; c < NV; c++) {
+    wv[c] = reinterpret_cast<const float4*>(w)[lane + 64 * c];
+    bv[c] = reinterpret_cast<const float4*>(b)[lane + 64 * c];
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NV; c++) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NV; c++) {
+    const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
+    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+  const float rstd = rsqrtf(q / (float)D + eps);
+#pragma unroll
+  for (int c = 0; c < NV; c++) {
+    float4 y;
+    y.x = (v[c].x - mean) * rstd * wv[c].x + bv[c].x;
+    y.y = (v[c].y - mean) * rstd * wv[c].y + bv[c].y;
+    y.z = (v[c].z - mean) * rstd * wv[c].z + bv[c].z;
+    y.w = (v[c].w - mean) * rstd * wv[c].w + bv[c].w;
+    if (out_bf) {
+      bf16x4 o;
+      o[0] = (bf16)y.x; o[1] = (bf16)y.y; o[2] = (bf16)y.z; o[3] = (bf16)y.w;
+      reinterpret_cast<bf16x4*>(out_bf + (size_t)row * D)[lane + 64 * c] = o;
+    }
+    if (out_f) reinterpret_cast<float4*>(out_f + (size_t)row * D)[lane + 64 * c] = y;
+  }
+}
+
+static void launch_layernorm(const float* x, const float* w, const float* b, bf16* out_bf, float* out_f, int rows, int D,
+                             float eps, hipStream_t s) {
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (D == 1024) hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, block, 0, s, x, w, b, out_bf, out_f, rows, eps);
+  else if (D == 768) hipLaunchKernelGGL(layernorm_vec_kernel<3>, grid, block, 0, s, x, w, b, out_bf, out_f, rows, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, x, w, b, out_bf, out_f, rows, D, eps);
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t n) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
@@ -283,8 +342,7 @@ static GemmArgs dense_args(const bf16* A, int M, const Lin& l) {
 
 static void layernorm(Ctx& c, const float* x, const Norm& n, int rows, bf16* out_bf, float* out_f) {
   if (c.dry() || c.rc) return;
-  hipLaunchKernelGGL(layernorm_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, c.s, x, n.w, n.b, out_bf, out_f, rows,
-                     n.d, 1e-6f);
+  launch_layernorm(x, n.w, n.b, out_bf, out_f, rows, n.d, 1e-6f, c.s);
   dbg(c, "layernorm", rows, n.d);
 }
 
@@ -380,7 +438,7 @@ static GemmArgs conv_args(const bf16* in, int B, int H, int W, int C, const Lin&
   const int pad = ks / 2;
   const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
   g.A = in; g.W = l.W; g.M = B * Ho * Wo; g.N = l.out; g.K = ks * ks * C; g.bias = l.b;
-  g.a_conv = 1; g.cH = H; g.cW = W; g.cC = C; g.cKs = ks; g.cStride = stride; g.cPad = pad; g.cHo = Ho; g.cWo = Wo;
+  g.a_conv = 1; g.cB = B; g.cH = H; g.cW = W; g.cC = C; g.cKs = ks; g.cStride = stride; g.cPad = pad; g.cHo = Ho; g.cWo = Wo;
   g.ldc = l.out; g.ldr1 = l.out; g.ldr2 = l.out; g.out_kind = KIND_BF16;
   return g;
 }
@@ -770,8 +828,7 @@ extern "C" int mslam_layernorm_f32(const float* x, const float* w, const float* 
                                    int rows, int D, float eps, void* stream) {
   MSLAM_REQUIRE(x && w && b && (out_bf16 || out_f32), "layernorm: null pointer");
   MSLAM_REQUIRE(D <= 2048 && rows > 0, "layernorm: D=%d must be <= 2048", D);
-  hipLaunchKernelGGL(layernorm_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b,
-                     (bf16*)out_bf16, out_f32, rows, D, eps);
+  launch_layernorm(x, w, b, (bf16*)out_bf16, out_f32, rows, D, eps, (hipStream_t)stream);
   MSLAM_LAUNCH_CHECK("layernorm");
   return MSLAM_OK;
 }
