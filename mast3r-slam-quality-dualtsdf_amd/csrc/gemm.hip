@@ -1,444 +1,13 @@
-// bf16 MFMA GEMM kernel (see gemm.h).  256 threads = 4 waves in a 2x2 arrangement; each wave owns
-// MI x NI tiles of 32x32 (v_mfma_f32_32x32x16_bf16, fp32 accumulators in registers).
-//   block tile BM x BN = (64*MI) x (64*NI), BK = 64 (128-byte rows), S-stage ring in LDS.
-//   Staging is LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass, out-of-range
-//   rows / K tail / conv padding are zero-filled by the buffer range check (no masking ALU).
-//   One wave-instruction writes 8 rows x 128 B lane-linearly, so the bank swizzle is applied on the
-//   SOURCE side: LDS slot s of row r holds K-chunk s ^ ((r >> 1) & 7); the fragment ds_read_b128 of 16
-//   consecutive rows then covers all 16 sixteen-byte slots of the 256-byte bank row (conflict-free).
-//   Pipeline: tiles kt+1 .. kt+S-2 stay in flight across the barrier (counted s_waitcnt vmcnt(N), raw
-//   s_barrier - a __syncthreads() fence would drain the DMA queue); one barrier per K tile.
+// Host-side dispatch of the bf16 MFMA GEMM (kernel: gemm_kernel.h, instantiations: gemm_t*.hip).
 #include <stdlib.h>
-#include <type_traits>
-#include <utility>
 #include "common.h"
 #include "gemm.h"
 
 namespace mslam {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) short short8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-constexpr int BK = 64;
-constexpr unsigned kOob = 0x80000000u;  // byte offset beyond any buffer (all operands are < 2 GiB): reads as zero
-
-#define MSLAM_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-__device__ __forceinline__ float bf16_to_f32(bf16 v) { return (float)v; }
-
-template <int... Is, typename F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-
-// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt = simm16[15:14]:[3:0], expcnt [6:4], lgkmcnt [11:8])
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
-  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
-}
-
-template <int MI, int NI, int S, bool CONV, bool RELU_A>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
-  constexpr int BM = 64 * MI, BN = 64 * NI;
-  constexpr int A_PC = BM / 32, B_PC = BN / 32;     // 1-KiB DMA pieces (8 rows x 128 B) per wave per tile
-  constexpr int N_DMA = A_PC + B_PC;                // DMA instructions per wave per tile
-  constexpr int STAGE = (BM + BN) * 128;            // bytes per ring stage
-  static_assert(S >= 3 && S <= 8, "ring depth");
-  static_assert(N_DMA * (S - 1) < 64, "vmcnt range");
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [S][BM + BN][128 B]
-
-  // XCD-aware tile order: blocks sharing an XCD get neighbouring tiles (same A rows / W panel in L2)
-  const unsigned nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
-  const unsigned tile = xcd_remap(blockIdx.x, nbm * nbn);
-  const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
-
-  const int t = threadIdx.x, lane = t & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-
-  // early, latency-hidden loads for the epilogue
-  const int lcol = lane & 31;
-  float bias_v[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ni++) {
-    const int col = n0 + wn * NI * 32 + ni * 32 + lcol;
-    bias_v[ni] = (g.bias && col < g.N) ? g.bias[g.epi == EPI_CONVT ? col / (g.ct_s * g.ct_s) : col] : 0.0f;
-  }
-
-  // ---- DMA source addressing -----------------------------------------------------------------
-  // piece q = wid + 4*i covers tile rows 8q .. 8q+7; lane -> row 8q + (lane >> 3), LDS slot lane & 7,
-  // which holds K-chunk c = slot ^ ((row >> 1) & 7) = slot ^ (4*(wid & 1) + (lane >> 4)).
-  const int chunk = (lane & 7) ^ (4 * (wid & 1) + (lane >> 4));
-  const size_t a_bytes = CONV ? (size_t)g.cB * g.cH * g.cW * g.cC * 2 : ((size_t)(g.M - 1) * g.lda + g.K) * 2;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW =
-      __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (int)((size_t)g.N * g.K * 2), 0x00020000);
-  unsigned a_off[A_PC];   // dense: byte offset of (row, chunk) at k0 = 0, or kOob; conv: byte offset of the image
-  int a_iy0[A_PC], a_ix0[A_PC];
-#pragma unroll
-  for (int i = 0; i < A_PC; i++) {
-    const int m = m0 + (wid + 4 * i) * 8 + (lane >> 3);
-    if constexpr (CONV) {
-      const int hw = g.cHo * g.cWo;
-      const int b = m / hw, rem = m - b * hw;
-      const int oy = rem / g.cWo, ox = rem - oy * g.cWo;
-      a_iy0[i] = (m < g.M) ? oy * g.cStride - g.cPad : -(1 << 20);   // invalid row: every tap out of range
-      a_ix0[i] = ox * g.cStride - g.cPad;
-      a_off[i] = (unsigned)b * (unsigned)(g.cH * g.cW * g.cC) * 2u;
-    } else {
-      a_off[i] = (m < g.M) ? ((unsigned)m * (unsigned)g.lda + (unsigned)chunk * 8u) * 2u : kOob;
-      a_iy0[i] = a_ix0[i] = 0;
-    }
-  }
-  unsigned b_off[B_PC];
-#pragma unroll
-  for (int i = 0; i < B_PC; i++) {
-    const int n = n0 + (wid + 4 * i) * 8 + (lane >> 3);
-    b_off[i] = (n < g.N) ? ((unsigned)n * (unsigned)g.K + (unsigned)chunk * 8u) * 2u : kOob;
-  }
-  // conv: (tap, channel) of this lane's chunk in the NEXT tile to be issued, advanced by 64 per tile
-  int c_cc = 0, c_dy = 0, c_dx = 0;
-  if constexpr (CONV) {
-    const int kk = chunk * 8, tap = kk / g.cC;
-    c_cc = kk - tap * g.cC;
-    c_dy = tap / g.cKs;
-    c_dx = tap - c_dy * g.cKs;
-  }
-
-  const int nk = (g.K + BK - 1) / BK;
-  // issue tile `kt` into ring stage `st` (tiles are issued in increasing kt order, exactly once each)
-  auto issue = [&](int st, int kt) {
-    unsigned char* sbase = smem + st * STAGE + wid * 1024;
-    const int k0 = kt * BK;
-    // Validity is folded into the offset with sign-bit arithmetic (bit 31 set = out of range = zero fill).
-    // A select here would be turned into divergent control flow around the DMA instruction, which both
-    // doubles the instruction count and breaks the vmcnt bookkeeping below.
-    const unsigned k_bad = (unsigned)(g.K - 1 - (k0 + chunk * 8)) & kOob;   // set only in a partial last tile
-#pragma unroll
-    for (int i = 0; i < A_PC; i++) {
-      unsigned off;
-      if constexpr (CONV) {
-        const int iy = a_iy0[i] + c_dy, ix = a_ix0[i] + c_dx;
-        const unsigned bad = (unsigned)(iy | (g.cH - 1 - iy) | ix | (g.cW - 1 - ix)) & kOob;
-        off = (a_off[i] + (unsigned)((iy * g.cW + ix) * g.cC + c_cc) * 2u) | bad | k_bad;
-      } else {
-        off = (a_off[i] + (unsigned)k0 * 2u) | k_bad;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, MSLAM_LDS_PTR(sbase + i * 4096), 16, off, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < B_PC; i++) {
-      const unsigned off = (b_off[i] + (unsigned)k0 * 2u) | k_bad;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, MSLAM_LDS_PTR(sbase + BM * 128 + i * 4096), 16, off, 0, 0, 0);
-    }
-    if constexpr (CONV) {
-      c_cc += BK;
-      while (c_cc >= g.cC) {
-        c_cc -= g.cC;
-        if (++c_dx == g.cKs) { c_dx = 0; c_dy++; }
-      }
-    }
-  };
-
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.0f;
-
-  // fragment addressing: row lr of the wave's 32-row slab, K half h; slot = (2*ks + h) ^ ((lr >> 1) & 7)
-  const int lr = lane & 31, kh = (lane >> 5) ^ ((lr >> 1) & 7);
-  const unsigned fragA = (wm * MI * 32 + lr) * 128, fragB = BM * 128 + (wn * NI * 32 + lr) * 128;
-  auto compute = [&](int st) {
-    const unsigned char* sA = smem + st * STAGE + fragA;
-    const unsigned char* sB = smem + st * STAGE + fragB;
-    // all fragment reads of the tile are issued before its first MFMA: a wave then pays the LDS latency
-    // once per tile instead of once per 16-deep step (the MFMAs wait on counted lgkmcnt)
-    constexpr int KS = BK / 16;
-    bf16x8 af[KS][MI], bfr[KS][NI];
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-      const int so = ((2 * ks) ^ kh) * 16;
-#pragma unroll
-      for (int mi = 0; mi < MI; mi++) af[ks][mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 4096 + so);
-#pragma unroll
-      for (int ni = 0; ni < NI; ni++) bfr[ks][ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 4096 + so);
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler would re-serialise them)
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-#pragma unroll
-      for (int mi = 0; mi < MI; mi++) {
-        if constexpr (RELU_A) {  // pre-activation of the DPT residual units: max(x, 0) on the int16 view
-          const short8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-          af[ks][mi] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(short8, af[ks][mi]), z));
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bfr[ks][ni], acc[mi][ni], 0, 0, 0);
-      }
-    }
-  };
-
-  // ---- main loop -----------------------------------------------------------------------------
-#pragma unroll
-  for (int s = 0; s < S - 1; s++)
-    if (s < nk) issue(s, s);
-  int kt = 0, st = 0, st_issue = S - 1;   // st = kt % S, st_issue = (kt + S - 1) % S
-  for (; kt < nk - (S - 2); kt++) {
-    wait_vmcnt<N_DMA * (S - 2)>();         // tile kt has landed (this wave's pieces); kt+1 .. kt+S-2 in flight
-    __builtin_amdgcn_s_barrier();          // everyone's pieces landed; everyone is done reading stage (kt-1) % S
-    if (kt + S - 1 < nk) issue(st_issue, kt + S - 1);
-    compute(st);
-    st = (st + 1 == S) ? 0 : st + 1;
-    st_issue = (st_issue + 1 == S) ? 0 : st_issue + 1;
-  }
-  for (; kt < nk; kt++) {                  // drain: nk-1-kt tiles still in flight behind this one
-    const int behind = nk - 1 - kt;        // < S-2 here
-    bool waited = false;
-    static_for<S - 3>([&](auto j_c) {
-      constexpr int b = decltype(j_c)::value + 1;
-      if (behind == b) { wait_vmcnt<N_DMA * b>(); waited = true; }
-    });
-    if (!waited) wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    compute(st);
-    st = (st + 1 == S) ? 0 : st + 1;
-  }
-
-  // ---- epilogue ------------------------------------------------------------------------------
-  // Every accumulator index below is a compile-time constant (static_for): a runtime-indexed
-  // ext_vector array would be demoted to scratch memory and spilled inside the K loop.
-  // The MFMA C layout has one COLUMN per lane, i.e. 2-byte scattered stores; a 32x32 tile is therefore
-  // turned through a per-wave LDS patch (the ring is free now) so that every lane owns 8 consecutive
-  // columns of a row: 16-byte loads of the residuals, 16-byte stores of the result.
-  __builtin_amdgcn_s_barrier();   // all waves are done reading the ring (every DMA was waited for above)
-  constexpr int TBS = 40;         // patch row stride in floats (16-byte aligned rows)
-  float* tb = reinterpret_cast<float*>(smem) + wid * (32 * TBS);
-  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8s;
-  const int half = lane >> 5;
-  const int lrow0 = lane >> 2, lc = (lane & 3) * 8;
-  const bool wide_plain = g.epi == EPI_PLAIN && (g.N & 7) == 0 && (g.ldc & 7) == 0 && (g.ldr1 & 7) == 0 && (g.ldr2 & 7) == 0;
-  const bool wide_attn = g.epi == EPI_ATTN && (g.ntok & 31) == 0 && (g.kv_ntok & 31) == 0;
-  auto load8 = [&](const void* base, int kind, size_t idx, float (&o)[8]) {
-    if (kind == KIND_F32) {
-      const float4 p = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
-      const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx + 4);
-      o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; o[4] += q.x; o[5] += q.y; o[6] += q.z; o[7] += q.w;
-    } else if (kind == KIND_BF16) {
-      const bf16x8s p = *reinterpret_cast<const bf16x8s*>(reinterpret_cast<const bf16*>(base) + idx);
-#pragma unroll
-      for (int e = 0; e < 8; e++) o[e] += (float)p[e];
-    }
-  };
-  static_for<MI>([&](auto mi_c) {
-    static_for<NI>([&](auto ni_c) {
-      constexpr int mi = decltype(mi_c)::value, ni = decltype(ni_c)::value;
-      const f32x16 accv = acc[mi][ni];
-      const int col_base = n0 + wn * NI * 32 + ni * 32;
-      const int col = col_base + lcol;
-      const int row_base0 = m0 + wm * MI * 32 + mi * 32;
-      const int row_base = row_base0 + 4 * half;
-      const bool col_ok = col < g.N;
-      const float bias = bias_v[ni];
-      float v[16];
-      static_for<16>([&](auto r_c) {
-        constexpr int r = decltype(r_c)::value;
-        float x = accv[r] + bias;
-        if (g.act == ACT_GELU) x = gelu_erf(x);
-        else if (g.act == ACT_RELU) x = fmaxf(x, 0.0f);
-        v[r] = x;
-      });
-      if (wide_plain) {
-        static_for<16>([&](auto r_c) {
-          constexpr int r = decltype(r_c)::value;
-          tb[((r & 3) + 8 * (r >> 2) + 4 * half) * TBS + lcol] = v[r];
-        });
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const int lrow = lrow0 + 16 * j;
-          const float4 p = *reinterpret_cast<const float4*>(tb + lrow * TBS + lc);
-          const float4 q = *reinterpret_cast<const float4*>(tb + lrow * TBS + lc + 4);
-          const int row = row_base0 + lrow, c0 = col_base + lc;
-          if (row < g.M && c0 < g.N) {
-            float o[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
-            load8(g.res1, g.res1_kind, (size_t)row * g.ldr1 + c0, o);
-            load8(g.res2, g.res2_kind, (size_t)row * g.ldr2 + c0, o);
-            if (g.out_kind == KIND_F32) {
-              float* dst = reinterpret_cast<float*>(g.out) + (size_t)row * g.ldc + c0;
-              *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-              *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-            } else {
-              bf16x8s pk;
-#pragma unroll
-              for (int e = 0; e < 8; e++) pk[e] = (bf16)o[e];
-              *reinterpret_cast<bf16x8s*>(reinterpret_cast<bf16*>(g.out) + (size_t)row * g.ldc + c0) = pk;
-            }
-          }
-        }
-      } else if (wide_attn) {
-        // a 32-wide tile is one RoPE half of one head; a 32-row tile lies inside one image (ntok % 32 == 0)
-        const int sec = g.sec_base + col_base / g.sec_dim;
-        const int cs = col_base % g.sec_dim;
-        const int head = cs >> 6, f0 = cs & 63;   // f0 = 0 or 32
-        const int ntok = (sec == 0) ? g.ntok : g.kv_ntok;
-        const int b = row_base0 / ntok, nb = row_base0 - b * ntok;
-        if (sec < 2) {
-          const bool use_y = f0 < 32;
-          const bool lo = lcol < 16;
-          const float scale = (sec == 0) ? g.q_scale : 1.0f;
-          static_for<16>([&](auto r_c) {
-            constexpr int r = decltype(r_c)::value;
-            const int n = nb + 4 * half + (r & 3) + 8 * (r >> 2);
-            const float partner = __shfl_xor(v[r], 16, 64);
-            const int p = use_y ? n / g.tok_w : n % g.tok_w;
-            const float c = g.rope_cos[p * 16 + (lcol & 15)], sn = g.rope_sin[p * 16 + (lcol & 15)];
-            const float x = lo ? (v[r] * c - partner * sn) : (v[r] * c + partner * sn);
-            tb[((r & 3) + 8 * (r >> 2) + 4 * half) * TBS + lcol] = x * scale;
-          });
-          bf16* dst = (sec == 0) ? g.q_out : g.k_out;
-#pragma unroll
-          for (int j = 0; j < 2; j++) {
-            const int lrow = lrow0 + 16 * j;
-            const float4 p = *reinterpret_cast<const float4*>(tb + lrow * TBS + lc);
-            const float4 q = *reinterpret_cast<const float4*>(tb + lrow * TBS + lc + 4);
-            if (row_base0 + lrow < g.M && col_base < g.N) {
-              bf16x8s pk;
-              pk[0] = (bf16)p.x; pk[1] = (bf16)p.y; pk[2] = (bf16)p.z; pk[3] = (bf16)p.w;
-              pk[4] = (bf16)q.x; pk[5] = (bf16)q.y; pk[6] = (bf16)q.z; pk[7] = (bf16)q.w;
-              *reinterpret_cast<bf16x8s*>(dst + (((size_t)b * g.heads + head) * ntok + nb + lrow) * 64 + f0 + lc) = pk;
-            }
-          }
-        } else {
-          // v, transposed per head: lane = feature f, 16 consecutive tokens -> two 16-byte stores
-          static_for<16>([&](auto r_c) {
-            constexpr int r = decltype(r_c)::value;
-            tb[((r & 3) + 8 * (r >> 2) + 4 * half) * TBS + lcol] = v[r];
-          });
-          const int tok0 = half * 16;
-          if (row_base0 + tok0 < g.M && col_ok) {
-            bf16x8s pk0, pk1;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-              pk0[e] = (bf16)tb[(tok0 + e) * TBS + lcol];
-              pk1[e] = (bf16)tb[(tok0 + 8 + e) * TBS + lcol];
-            }
-            bf16* dst = g.vt_out + (((size_t)b * g.heads + head) * 64 + f0 + lcol) * ntok + nb + tok0;
-            *reinterpret_cast<bf16x8s*>(dst) = pk0;
-            *reinterpret_cast<bf16x8s*>(dst + 8) = pk1;
-          }
-        }
-      } else {
-        if (g.epi == EPI_PLAIN) {
-          static_for<16>([&](auto r_c) {
-            constexpr int r = decltype(r_c)::value;
-            const int row = row_base + (r & 3) + 8 * (r >> 2);
-            if (row < g.M && col_ok) {
-              float x = v[r];
-              if (g.res1_kind == KIND_F32) x += reinterpret_cast<const float*>(g.res1)[(size_t)row * g.ldr1 + col];
-              else if (g.res1_kind == KIND_BF16) x += bf16_to_f32(reinterpret_cast<const bf16*>(g.res1)[(size_t)row * g.ldr1 + col]);
-              if (g.res2_kind == KIND_F32) x += reinterpret_cast<const float*>(g.res2)[(size_t)row * g.ldr2 + col];
-              else if (g.res2_kind == KIND_BF16) x += bf16_to_f32(reinterpret_cast<const bf16*>(g.res2)[(size_t)row * g.ldr2 + col]);
-              if (g.out_kind == KIND_F32) reinterpret_cast<float*>(g.out)[(size_t)row * g.ldc + col] = x;
-              else reinterpret_cast<bf16*>(g.out)[(size_t)row * g.ldc + col] = (bf16)x;
-            }
-          });
-        } else if (g.epi == EPI_ATTN) {
-          // column -> (section, head, feature); a 32-wide MFMA tile is exactly one RoPE half of one head
-          const int sec = g.sec_base + col / g.sec_dim;
-          const int cs = col % g.sec_dim;
-          const int head = cs >> 6, f = cs & 63;
-          const int ntok = (sec == 0) ? g.ntok : g.kv_ntok;
-          if (sec < 2) {
-            const bool use_y = f < 32;
-            const bool lo = (f & 31) < 16;
-            bf16* dst = (sec == 0) ? g.q_out : g.k_out;
-            const float scale = (sec == 0) ? g.q_scale : 1.0f;
-            static_for<16>([&](auto r_c) {
-              constexpr int r = decltype(r_c)::value;
-              const int row = row_base + (r & 3) + 8 * (r >> 2);
-              const float partner = __shfl_xor(v[r], 16, 64);
-              if (row < g.M && col_ok) {
-                const int b = row / ntok, n = row - b * ntok;
-                const int p = use_y ? n / g.tok_w : n % g.tok_w;
-                const float c = g.rope_cos[p * 16 + (f & 15)], sn = g.rope_sin[p * 16 + (f & 15)];
-                const float x = lo ? (v[r] * c - partner * sn) : (v[r] * c + partner * sn);
-                dst[(((size_t)b * g.heads + head) * ntok + n) * 64 + f] = (bf16)(x * scale);
-              }
-            });
-          } else {
-            // v: transposed per head, 4 consecutive tokens per 8-byte store
-            static_for<4>([&](auto gq_c) {
-              constexpr int gq = decltype(gq_c)::value;
-              const int row = row_base + 8 * gq;  // rows row..row+3 (registers 4gq..4gq+3)
-              if (row < g.M && col_ok) {
-                const int b = row / ntok, n = row - b * ntok;
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-                bf16x4 pk;
-                pk[0] = (bf16)v[4 * gq + 0]; pk[1] = (bf16)v[4 * gq + 1];
-                pk[2] = (bf16)v[4 * gq + 2]; pk[3] = (bf16)v[4 * gq + 3];
-                *reinterpret_cast<bf16x4*>(g.vt_out + (((size_t)b * g.heads + head) * 64 + f) * ntok + n) = pk;
-              }
-            });
-          }
-        } else {  // EPI_CONVT: n = co*s*s + i*s + j ; m = (b, y, x) -> out[b, y*s+i, x*s+j, co]
-          const int ss = g.ct_s * g.ct_s;
-          const int co = col / ss, ij = col - co * ss, i = ij / g.ct_s, j = ij - i * g.ct_s;
-          static_for<16>([&](auto r_c) {
-            constexpr int r = decltype(r_c)::value;
-            const int row = row_base + (r & 3) + 8 * (r >> 2);
-            if (row < g.M && col_ok) {
-              const int hw = g.ct_h * g.ct_w;
-              const int b = row / hw, rem = row - b * hw, y = rem / g.ct_w, x = rem - y * g.ct_w;
-              const size_t o = (((size_t)b * g.ct_h * g.ct_s + (size_t)y * g.ct_s + i) * (g.ct_w * g.ct_s) +
-                                (size_t)x * g.ct_s + j) * g.ct_cout + co;
-              reinterpret_cast<bf16*>(g.out)[o] = (bf16)v[r];
-            }
-          });
-        }
-      }
-    });
-  });
-}
-
-// ---- host side -------------------------------------------------------------------------------
-namespace {
-
-struct TileCfg { int bm, bn, stages; };
-
-template <int MI, int NI, int S>
-int launch_cfg(const GemmArgs& a, hipStream_t stream) {
-  constexpr int BM = 64 * MI, BN = 64 * NI;
-  constexpr size_t shmem = (size_t)S * (BM + BN) * 128;
-  const unsigned blocks = (unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN));
-  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
-  if (!attr_set) {
-    const void* fns[3] = {(const void*)gemm_bf16_kernel<MI, NI, S, false, false>,
-                          (const void*)gemm_bf16_kernel<MI, NI, S, true, false>,
-                          (const void*)gemm_bf16_kernel<MI, NI, S, true, true>};
-    for (const void* fn : fns) {
-      int rc = check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem), "gemm: attr");
-      if (rc) return rc;
-    }
-    attr_set = true;
-  }
-  if (!a.a_conv) hipLaunchKernelGGL((gemm_bf16_kernel<MI, NI, S, false, false>), dim3(blocks), dim3(256), shmem, stream, a);
-  else if (!a.a_relu) hipLaunchKernelGGL((gemm_bf16_kernel<MI, NI, S, true, false>), dim3(blocks), dim3(256), shmem, stream, a);
-  else hipLaunchKernelGGL((gemm_bf16_kernel<MI, NI, S, true, true>), dim3(blocks), dim3(256), shmem, stream, a);
-  return check_hip(hipGetLastError(), "gemm launch");
-}
-
-}  // namespace
+int launch_gemm_t64(const GemmArgs& a, int stages, hipStream_t s);
+int launch_gemm_t128(const GemmArgs& a, int waves, int stages, hipStream_t s);
+int launch_gemm_t256(const GemmArgs& a, int bn, hipStream_t s);
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   MSLAM_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %dx%dx%d", a.M, a.N, a.K);
@@ -451,27 +20,37 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   MSLAM_REQUIRE(a_bytes < (1ull << 31) && (size_t)a.N * a.K * 2 < (1ull << 31), "gemm: operand larger than 2 GiB");
   MSLAM_REQUIRE(a.epi != EPI_ATTN || (a.sec_dim % 64 == 0 && a.ntok % 4 == 0 && a.kv_ntok % 4 == 0),
                 "gemm: attention epilogue needs 64-wide heads and token counts divisible by 4");
-  // Tile selection: the largest tile that still gives the chip enough blocks.  MSLAM_GEMM="<tile>" forces
-  // one (0: 64x64 ring 8, 1: 128x64, 2: 128x128, 3: 256x128, 4: 64x64 ring 4) for experiments (tools/bench_kernels.py).
+  // Tile selection (measured on MI355X, tools/gemm_tune.py).  What a CU can pull into LDS grows with the
+  // number of waves issuing DMA, not with the ring depth, so every configuration keeps several blocks
+  // (or many waves) per CU: shallow rings, 32-64 KiB of LDS per 4 waves.  Larger tiles halve the L2->LDS
+  // traffic and win as soon as they still cover the chip.
+  // MSLAM_GEMM="<cfg>" forces one configuration for experiments:
+  //   642/643/644: 64x64 ring 2/3/4; 1242: 128x128 4 waves; 1282/1283: 128x128 8 waves ring 2/3;
+  //   2128: 256x128 8 waves; 2256: 256x256 16 waves
   static int forced = -2;
   if (forced == -2) {
     const char* e = getenv("MSLAM_GEMM");
     forced = e ? atoi(e) : -1;
   }
   auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-  int pick;
-  if (forced >= 0) pick = forced;
-  else if (blocks(256, 128) >= 512) pick = 3;
-  else if (blocks(128, 128) >= 128) pick = 2;
-  else pick = 0;
-  // Ring depth: the LDS-DMA round trip is ~1 us, so a CU needs ~100 KiB in flight to keep its 64 B/clk
-  // fill path busy; every configuration spends 120-144 KiB of the 160 KiB LDS on the ring.
-  switch (pick) {
-    case 3: return launch_cfg<4, 2, 3>(a, stream);
-    case 2: return launch_cfg<2, 2, 4>(a, stream);
-    case 1: return launch_cfg<2, 1, 5>(a, stream);
-    case 4: return launch_cfg<1, 1, 4>(a, stream);
-    default: return launch_cfg<1, 1, 8>(a, stream);
+  int cfg = forced;
+  if (cfg < 0) {
+    if (blocks(256, 256) >= 128) cfg = 2256;
+    else if (blocks(128, 128) >= 300) cfg = 1282;
+    else if (blocks(64, 64) >= 512) cfg = 642;
+    else if (a.K >= 2048) cfg = 644;
+    else cfg = 643;
+  }
+  switch (cfg) {
+    case 642: return launch_gemm_t64(a, 2, stream);
+    case 643: return launch_gemm_t64(a, 3, stream);
+    case 644: return launch_gemm_t64(a, 4, stream);
+    case 1242: return launch_gemm_t128(a, 4, 2, stream);
+    case 1282: return launch_gemm_t128(a, 8, 2, stream);
+    case 1283: return launch_gemm_t128(a, 8, 3, stream);
+    case 2128: return launch_gemm_t256(a, 128, stream);
+    case 2256: return launch_gemm_t256(a, 256, stream);
+    default: MSLAM_REQUIRE(false, "gemm: unknown configuration %d", cfg);
   }
 }
 
