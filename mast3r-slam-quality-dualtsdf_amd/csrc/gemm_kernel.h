@@ -38,7 +38,19 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erfc from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far
+// inside the bf16 output rounding): 1 rcp + 1 exp2 + 8 fma instead of the ~40-instruction libm erff.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erfc(|x| / sqrt 2)
+  const float one_plus_erf = (x >= 0.0f) ? 2.0f - erfc_z : erfc_z;
+  return 0.5f * x * one_plus_erf;
+}
 
 // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt = simm16[15:14]:[3:0], expcnt [6:4], lgkmcnt [11:8])
 template <int N>
