@@ -23,6 +23,7 @@
 //                      the matching A operand comes from the V^T tile with two 8-byte LDS reads
 //   q arrives RoPE-rotated and pre-scaled by d^-1/2, k RoPE-rotated, v transposed per head: all three
 //   are written in that form by the projection GEMM's epilogue (gemm_kernel.h, EPI_ATTN).
+#include <stdlib.h>
 #include "common.h"
 #include "gemm.h"
 
@@ -34,9 +35,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int KV_TILE = 64;
-constexpr int AT_SPLIT = 4;               // key splits per block
 constexpr int AT_STAGE = 16384;           // K tile (64 x 128 B) + V^T tile (64 x 128 B)
-constexpr int AT_RING = AT_SPLIT * 2 * AT_STAGE;
 constexpr int OM_ROW = 68;                // floats per (wave, query) row of the merge buffer
 constexpr unsigned kAtOob = 0x80000000u;
 
@@ -47,7 +46,10 @@ __device__ __forceinline__ void at_wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
 }
 
-__global__ __launch_bounds__(512) void attention_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+// AT_SPLIT key splits per block (2 * AT_SPLIT waves): 4 when the grid would otherwise leave SIMDs idle,
+// fewer (less LDS, several blocks per CU) for the batched backend calls.
+template <int AT_SPLIT>
+__global__ __launch_bounds__(128 * AT_SPLIT) void attention_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                         const bf16* __restrict__ VT, bf16* __restrict__ O,
                                                         int heads, int nq, int nk) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // ring, later the merge buffer
@@ -194,8 +196,9 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16* __restrict__
 
   // ---- merge the four key splits ---------------------------------------------------------------
   __builtin_amdgcn_s_barrier();     // the ring is free
-  float* Om = reinterpret_cast<float*>(smem);                       // [8 waves][32 q][OM_ROW]
-  float* ml = Om + 8 * 32 * OM_ROW;                                 // [8 waves][32 q][2]
+  constexpr int NWV = 2 * AT_SPLIT;
+  float* Om = reinterpret_cast<float*>(smem);                       // [NWV waves][32 q][OM_ROW]
+  float* ml = Om + NWV * 32 * OM_ROW;                               // [NWV waves][32 q][2]
   if (h == 0) {
     ml[(wid * 32 + lq) * 2] = m_run;
     ml[(wid * 32 + lq) * 2 + 1] = l_run;
@@ -207,8 +210,8 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16* __restrict__
       *reinterpret_cast<float4*>(Om + (wid * 32 + lq) * OM_ROW + 32 * dt + 8 * gq + 4 * h) =
           make_float4(o_acc[dt][4 * gq], o_acc[dt][4 * gq + 1], o_acc[dt][4 * gq + 2], o_acc[dt][4 * gq + 3]);
   __syncthreads();
-  {
-    const int q = t >> 3, d0 = (t & 7) * 8;     // 64 queries x 8 feature octets
+  for (int e = t; e < 512; e += 128 * AT_SPLIT) {
+    const int q = e >> 3, d0 = (e & 7) * 8;     // 64 queries x 8 feature octets
     const int fq = q >> 5, ql = q & 31;
     float m_s[AT_SPLIT], m_max = -INFINITY;
 #pragma unroll
@@ -233,10 +236,28 @@ __global__ __launch_bounds__(512) void attention_kernel(const bf16* __restrict__
       const float inv = 1.0f / l_sum;
       bf16x8 pk;
 #pragma unroll
-      for (int e = 0; e < 8; e++) pk[e] = (bf16)(acc8[e] * inv);
+      for (int k = 0; k < 8; k++) pk[k] = (bf16)(acc8[k] * inv);
       *reinterpret_cast<bf16x8*>(O + ((size_t)b * nq + row) * ((size_t)heads * 64) + (size_t)head * 64 + d0) = pk;
     }
   }
+}
+
+template <int AT_SPLIT>
+static int launch_attention_split(const bf16* Q, const bf16* K, const bf16* VT, bf16* O, int batch, int heads, int nq,
+                                  int nk, hipStream_t stream) {
+  constexpr int ring = AT_SPLIT * 2 * AT_STAGE;
+  constexpr int merge = (2 * AT_SPLIT * 32 * OM_ROW + 2 * AT_SPLIT * 32 * 2) * (int)sizeof(float);
+  constexpr int shmem = ring > merge ? ring : merge;
+  static bool attr_set = false;
+  if (!attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)attention_kernel<AT_SPLIT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, shmem), "attention: attr");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  dim3 grid((nq + 63) / 64, heads, batch);
+  hipLaunchKernelGGL(attention_kernel<AT_SPLIT>, grid, dim3(128 * AT_SPLIT), shmem, stream, Q, K, VT, O, heads, nq, nk);
+  return check_hip(hipGetLastError(), "attention launch");
 }
 
 int launch_attention(const bf16* Q, const bf16* K, const bf16* VT, bf16* O, int batch, int heads, int nq, int nk,
@@ -244,17 +265,18 @@ int launch_attention(const bf16* Q, const bf16* K, const bf16* VT, bf16* O, int 
   MSLAM_REQUIRE(nq > 0 && nk > 0 && batch > 0 && heads > 0, "attention: empty problem");
   MSLAM_REQUIRE(nk % 8 == 0, "attention: key count %d must be a multiple of 8", nk);
   MSLAM_REQUIRE((size_t)nk * 128 < (1ull << 31), "attention: key count %d too large", nk);
-  static bool attr_set = false;
-  if (!attr_set) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AT_RING),
-                       "attention: attr");
-    if (rc) return rc;
-    attr_set = true;
+  static int forced = -2;   // MSLAM_ATTN_SPLIT=1|2|4 forces the key split (experiments)
+  if (forced == -2) {
+    const char* e = getenv("MSLAM_ATTN_SPLIT");
+    forced = e ? atoi(e) : -1;
   }
-  static_assert((8 * 32 * OM_ROW + 8 * 32 * 2) * sizeof(float) <= AT_RING, "merge buffer must fit in the ring");
-  dim3 grid((nq + 63) / 64, heads, batch);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(512), AT_RING, stream, Q, K, VT, O, heads, nq, nk);
-  return check_hip(hipGetLastError(), "attention launch");
+  const long blocks = (long)((nq + 63) / 64) * heads * batch;
+  const int split = forced > 0 ? forced : (blocks <= 256 ? 4 : 2);   // measured: tools/attn_tune.py
+  switch (split) {
+    case 4: return launch_attention_split<4>(Q, K, VT, O, batch, heads, nq, nk, stream);
+    case 2: return launch_attention_split<2>(Q, K, VT, O, batch, heads, nq, nk, stream);
+    default: return launch_attention_split<1>(Q, K, VT, O, batch, heads, nq, nk, stream);
+  }
 }
 
 }  // namespace mslam

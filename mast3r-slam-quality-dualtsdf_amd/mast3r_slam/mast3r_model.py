@@ -111,9 +111,14 @@ def canonical_weights(sd, cfg, device):
 
 
 class Mast3rHIP:
-    def __init__(self, state_dict, cfg: Mast3rConfig = None, device="cuda"):
+    def __init__(self, state_dict, cfg: Mast3rConfig = None, device="cuda", use_graphs=False):
+        """use_graphs: capture each (call, batch, H, W) once into a HIP graph and replay it (the forward is
+        ~800 short launches per frame, so the host launch path matters); inputs are copied into the graph's
+        static buffers and results are returned as fresh tensors, so call semantics do not change."""
         self.cfg = cfg or Mast3rConfig()
         self.device = torch.device(device)
+        self.use_graphs = bool(use_graphs)
+        self._graphs = {}
         self._weights = canonical_weights(state_dict, self.cfg, self.device)
         n = len(self._weights)
         ptrs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in self._weights])
@@ -142,13 +147,17 @@ class Mast3rHIP:
     def eval(self):
         return self
 
-    def _workspace(self, B, H, W):
+    def _workspace(self, B, H, W, kind="dec"):
+        """Arena for one call; encode and decode keep separate arenas so that the encoder of the next frame
+        may run on another stream while the current frame is decoded."""
         need = _m.lib().mslam_mast3r_workspace_bytes(self._h, B, H, W)
         if need == 0:
             _m.check(-1, "mast3r_workspace_bytes")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        if self._ws is None:
+            self._ws = {}
+        if kind not in self._ws or self._ws[kind].numel() < need:
+            self._ws[kind] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws[kind]
 
     def positions(self, B, H, W):
         """PositionGetter (croco/models/blocks.py:195-207): (B, N, 2) int64 [y, x]."""
@@ -162,36 +171,81 @@ class Mast3rHIP:
         image = image.to(self.device, torch.float32).contiguous()
         B, _, H, W = image.shape
         N = (H // self.cfg.patch) * (W // self.cfg.patch)
+        self._last_hw = (H, W)
+        if self.use_graphs:
+            return self._replay(("enc", B, H, W), (image,))[0].clone(), self.positions(B, H, W), None
         feat = torch.empty((B, N, self.cfg.enc_dim), dtype=torch.float32, device=self.device)
-        ws = self._workspace(B, H, W)
+        self._run_encode(image, feat, self._workspace(B, H, W, "enc"))
+        return feat, self.positions(B, H, W), None
+
+    def _run_encode(self, image, feat, ws):
+        B, _, H, W = image.shape
         rc = _m.lib().mslam_mast3r_encode(self._h, _m.ptr(image), B, H, W, _m.ptr(feat), _m.ptr(ws), ws.numel(),
                                          _m.stream_ptr())
         _m.check(rc, "mast3r_encode")
-        self._last_hw = (H, W)
-        return feat, self.positions(B, H, W), None
+
+    def _run_decode(self, feat1, feat2, H, W, outs, d1, d2, ws):
+        a, b = outs
+        rc = _m.lib().mslam_mast3r_decode(
+            self._h, _m.ptr(feat1), _m.ptr(feat2), feat1.shape[0], H, W, _m.ptr(a["pts3d"]), _m.ptr(a["conf"]),
+            _m.ptr(a["desc"]), _m.ptr(a["desc_conf"]), _m.ptr(b["pts3d"]), _m.ptr(b["conf"]), _m.ptr(b["desc"]),
+            _m.ptr(b["desc_conf"]), _m.ptr(d1), _m.ptr(d2), _m.ptr(ws), ws.numel(), _m.stream_ptr())
+        _m.check(rc, "mast3r_decode")
+
+    def _decode_buffers(self, B, H, W, N):
+        dd = self.cfg.desc_dim
+        f32 = dict(dtype=torch.float32, device=self.device)
+        outs = [dict(pts3d=torch.empty((B, H, W, 3), **f32), conf=torch.empty((B, H, W), **f32),
+                     desc=torch.empty((B, H, W, dd), **f32), desc_conf=torch.empty((B, H, W), **f32)) for _ in range(2)]
+        return outs, torch.empty((B, N, self.cfg.dec_dim), **f32), torch.empty((B, N, self.cfg.dec_dim), **f32)
+
+    def _replay(self, key, inputs):
+        """Graph cache: first use runs once eagerly (one-time kernel attribute calls), then captures."""
+        ent = self._graphs.get(key)
+        if ent is None:
+            kind, B, H, W = key
+            N = (H // self.cfg.patch) * (W // self.cfg.patch)
+            need = _m.lib().mslam_mast3r_workspace_bytes(self._h, B, H, W)
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)   # private: graphs may replay concurrently
+            static_in = [torch.empty_like(x) for x in inputs]
+            if kind == "enc":
+                feat = torch.empty((B, N, self.cfg.enc_dim), dtype=torch.float32, device=self.device)
+                run = lambda: self._run_encode(static_in[0], feat, ws)
+                outs = (feat,)
+            else:
+                o, d1, d2 = self._decode_buffers(B, H, W, N)
+                run = lambda: self._run_decode(static_in[0], static_in[1], H, W, o, d1, d2, ws)
+                outs = (o, d1, d2)
+            for dst, src in zip(static_in, inputs):
+                dst.copy_(src)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                run()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                run()
+            ent = self._graphs[key] = (g, static_in, outs, ws)
+        g, static_in, outs, _ = ent
+        for dst, src in zip(static_in, inputs):
+            dst.copy_(src)
+        g.replay()
+        return outs
 
     @torch.inference_mode()
     def decode_pair(self, feat1, feat2, H, W, return_tokens=False):
         """_decoder + both heads in one native call.  Returns (res1, res2[, dec_last1, dec_last2])."""
         feat1 = feat1.to(self.device, torch.float32).contiguous()
         feat2 = feat2.to(self.device, torch.float32).contiguous()
-        B = feat1.shape[0]
-        dd = self.cfg.desc_dim
-        f32 = dict(dtype=torch.float32, device=self.device)
-        outs = []
-        for _ in range(2):
-            outs.append(dict(pts3d=torch.empty((B, H, W, 3), **f32), conf=torch.empty((B, H, W), **f32),
-                             desc=torch.empty((B, H, W, dd), **f32), desc_conf=torch.empty((B, H, W), **f32)))
-        N = feat1.shape[1]
-        d1 = torch.empty((B, N, self.cfg.dec_dim), **f32)
-        d2 = torch.empty((B, N, self.cfg.dec_dim), **f32)
-        ws = self._workspace(B, H, W)
-        a, b = outs
-        rc = _m.lib().mslam_mast3r_decode(
-            self._h, _m.ptr(feat1), _m.ptr(feat2), B, H, W, _m.ptr(a["pts3d"]), _m.ptr(a["conf"]), _m.ptr(a["desc"]),
-            _m.ptr(a["desc_conf"]), _m.ptr(b["pts3d"]), _m.ptr(b["conf"]), _m.ptr(b["desc"]), _m.ptr(b["desc_conf"]),
-            _m.ptr(d1), _m.ptr(d2), _m.ptr(ws), ws.numel(), _m.stream_ptr())
-        _m.check(rc, "mast3r_decode")
+        B, N = feat1.shape[0], feat1.shape[1]
+        if self.use_graphs:
+            (a, b), d1, d2 = self._replay(("dec", B, H, W), (feat1, feat2))
+            a, b = {k: v.clone() for k, v in a.items()}, {k: v.clone() for k, v in b.items()}
+            d1, d2 = d1.clone(), d2.clone()
+        else:
+            (a, b), d1, d2 = self._decode_buffers(B, H, W, N)
+            self._run_decode(feat1, feat2, H, W, (a, b), d1, d2, self._workspace(B, H, W))
         if return_tokens:
             return a, b, d1, d2
         return a, b
