@@ -22,6 +22,8 @@ iteration; TSDF voxels are sharded by key hash, keyframe points are all-gathered
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import queue
+import threading
 import json
 import os
 import sys
@@ -52,6 +54,8 @@ def parse():
     ap.add_argument("--graph-kfs", type=int, default=8, help="keyframes in the backend graph PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graphs", action="store_true", help="replay the network as captured HIP graphs (default: eager)")
+    ap.add_argument("--no-backend-thread", action="store_true",
+                    help="run the keyframe backend inline in the tracking loop instead of on its own thread + stream")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="encode each frame inside its own step instead of one frame ahead on a second stream")
     ap.add_argument("--depth-scale", type=float, default=1.0, help="debug: <1 shrinks the network depth")
@@ -79,6 +83,39 @@ def barrier(world):
 
         dist.barrier()
     torch.cuda.synchronize()
+
+
+class BackendWorker(threading.Thread):
+    """The reference runs the backend (symmetric edge inference, global GN, TSDF) in a process of its own
+    beside the tracking frontend (main.py:73-163, tsdf_refine.py / global_manager.py threads); here it is a
+    host thread with its own HIP stream.  Every queued task is finished before the clock stops."""
+
+    def __init__(self, dev):
+        super().__init__(daemon=True)
+        self.q = queue.Queue()
+        self.dev = dev
+        self.error = None
+        self.start()
+
+    def run(self):
+        stream = torch.cuda.Stream(device=self.dev)
+        with torch.cuda.stream(stream):
+            while True:
+                task = self.q.get()
+                try:
+                    if task is None:
+                        return
+                    if self.error is None:
+                        task()
+                except Exception as e:  # surfaced by drain()
+                    self.error = e
+                finally:
+                    self.q.task_done()
+
+    def drain(self):
+        self.q.join()
+        if self.error is not None:
+            raise self.error
 
 
 class Pipeline:
@@ -156,9 +193,10 @@ class Pipeline:
             m[y0:y0 + 32, x0:x0 + 32] = True
             self.refine_blocks.append(PatchBlock(0, b, m.reshape(-1)))
         # frontend pipeline: the encoder of frame f+1 runs on its own stream beside decode/match/track of frame f
+        # multi-GPU: the backend issues collectives, keep them on the thread that owns the process group
+        self.worker = None if (args.no_backend_thread or world > 1) else BackendWorker(dev)
         self.enc_stream = torch.cuda.Stream(device=dev)
         self.next_feat, self.enc_done = None, None
-        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         self.net_ms = 0.0
         self.net_calls = 0
         self.timing = False
@@ -167,11 +205,11 @@ class Pipeline:
         """Run a network stage; when timing, bracket it with events on the launch stream."""
         if not self.timing:
             return fn()
-        self.ev[0].record()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # local: two host threads
+        e0.record()
         out = fn()
-        self.ev[1].record()
-        self._pending.append((self.ev[0], self.ev[1]))
-        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        e1.record()
+        self._pending.append((e0, e1))
         return out
 
     def step(self, f):
@@ -204,42 +242,53 @@ class Pipeline:
                                             valid[0], idx=idx[0])
         # ---- keyframe / backend -------------------------------------------------------------------
         if f % a.kf_every == 0:
-            self._net(lambda: self.model.decode_pair(self.feat_i, self.feat_j, H, W))
-            self._net(lambda: self.model.decode_pair(self.feat_j, self.feat_i, H, W))
-            E = a.edges_per_kf
-            X11 = torch.cat([p["X11"] for p in self.pairs] * E)[: 2 * E]
-            X21 = torch.cat([p["X21"] for p in self.pairs] * E)[: 2 * E]
-            D11 = torch.cat([p["D11"] for p in self.pairs] * E)[: 2 * E]
-            D21 = torch.cat([p["D21"] for p in self.pairs] * E)[: 2 * E]
-            matching.match(X11, X21, D11, D21)
-            g = self.graph
-            lc = c["local_opt"]
-            Twc = g["Twc"].clone()
-            if self.world > 1:
-                from mast3r_slam.global_opt import gauss_newton_sharded
-
-                gauss_newton_sharded("rays", Twc, g["Xs"], g["Cs"], None, g["ii"], g["jj"], g["idx_ii2jj"],
-                                     g["valid_match"], g["Q"], lc)
+            if self.worker is not None:
+                self.worker.q.put(self.backend)
             else:
-                be.gauss_newton_rays(Twc, g["Xs"], g["Cs"], g["ii"], g["jj"], g["idx_ii2jj"], g["valid_match"], g["Q"],
-                                     lc["sigma_ray"], lc["sigma_dist"], lc["C_conf"], lc["Q_conf"], lc["max_iters"],
-                                     lc["delta_norm"])
-            pts, conf, org = self.tsdf_pts, self.tsdf_conf, self.tsdf_org
-            if self.world > 1:
-                import torch.distributed as dist
+                self.backend()
 
-                gp = [torch.empty_like(pts) for _ in range(self.world)]
-                gc = [torch.empty_like(conf) for _ in range(self.world)]
-                go = [torch.empty_like(org) for _ in range(self.world)]
-                dist.all_gather(gp, pts); dist.all_gather(gc, conf); dist.all_gather(go, org)
-                for r in range(self.world):
-                    self.vol.integrate(gp[r], gc[r], go[r], return_fused=False)
-            else:
-                self.vol.integrate(pts, conf, org, return_fused=False)
-            self.tsdf_opt.refine_pose(Sim3(self.tsdf_pose), self.tsdf_cam_pts, self.tsdf_cam_conf, iterations=3)
-            self.refiner.keyframes[0].C.copy_(self.refine_C0)
-            for blk in self.refine_blocks:
-                self.refiner.refine_block(blk)
+    def backend(self):
+        from lietorch_hip import Sim3
+        from mast3r_slam import matching
+        import mast3r_slam_backends as be
+
+        a, c = self.args, self.cfg
+        self._net(lambda: self.model.decode_pair(self.feat_i, self.feat_j, H, W))
+        self._net(lambda: self.model.decode_pair(self.feat_j, self.feat_i, H, W))
+        E = a.edges_per_kf
+        X11 = torch.cat([p["X11"] for p in self.pairs] * E)[: 2 * E]
+        X21 = torch.cat([p["X21"] for p in self.pairs] * E)[: 2 * E]
+        D11 = torch.cat([p["D11"] for p in self.pairs] * E)[: 2 * E]
+        D21 = torch.cat([p["D21"] for p in self.pairs] * E)[: 2 * E]
+        matching.match(X11, X21, D11, D21)
+        g = self.graph
+        lc = c["local_opt"]
+        Twc = g["Twc"].clone()
+        if self.world > 1:
+            from mast3r_slam.global_opt import gauss_newton_sharded
+
+            gauss_newton_sharded("rays", Twc, g["Xs"], g["Cs"], None, g["ii"], g["jj"], g["idx_ii2jj"],
+                                 g["valid_match"], g["Q"], lc)
+        else:
+            be.gauss_newton_rays(Twc, g["Xs"], g["Cs"], g["ii"], g["jj"], g["idx_ii2jj"], g["valid_match"], g["Q"],
+                                 lc["sigma_ray"], lc["sigma_dist"], lc["C_conf"], lc["Q_conf"], lc["max_iters"],
+                                 lc["delta_norm"])
+        pts, conf, org = self.tsdf_pts, self.tsdf_conf, self.tsdf_org
+        if self.world > 1:
+            import torch.distributed as dist
+
+            gp = [torch.empty_like(pts) for _ in range(self.world)]
+            gc = [torch.empty_like(conf) for _ in range(self.world)]
+            go = [torch.empty_like(org) for _ in range(self.world)]
+            dist.all_gather(gp, pts); dist.all_gather(gc, conf); dist.all_gather(go, org)
+            for r in range(self.world):
+                self.vol.integrate(gp[r], gc[r], go[r], return_fused=False)
+        else:
+            self.vol.integrate(pts, conf, org, return_fused=False)
+        self.tsdf_opt.refine_pose(Sim3(self.tsdf_pose), self.tsdf_cam_pts, self.tsdf_cam_conf, iterations=3)
+        self.refiner.keyframes[0].C.copy_(self.refine_C0)
+        for blk in self.refine_blocks:
+            self.refiner.refine_block(blk)
 
     def network_probe(self, frames=6):
         """Kernel-quality figure for the roofline object: the network stages of `frames` tracked frames and
@@ -364,13 +413,17 @@ def main():
     pipe = Pipeline(args, rank, world, dev)
     for f in range(args.warmup):
         pipe.step(f)
+    if pipe.worker is not None:
+        pipe.worker.drain()
     barrier(world)
     pipe.timing = True
     pipe._pending = []
     t0 = time.perf_counter()
     for f in range(args.steps):
         pipe.step(f)
-    barrier(world)
+    if pipe.worker is not None:
+        pipe.worker.drain()   # every queued keyframe task has been issued ...
+    barrier(world)            # ... and (device-wide synchronise inside) has finished
     elapsed = time.perf_counter() - t0
     net_ms = sum(a.elapsed_time(b) for a, b in pipe._pending)
     pipe.timing = False
@@ -395,6 +448,7 @@ def main():
                                    f"every {args.kf_every} frames ({args.edges_per_kf} symmetric edges, "
                                    f"{args.graph_kfs * world}-keyframe GN graph, 40k-point TSDF fuse)",
                        "weights": "random-init ViT-L/12+12 MASt3R architecture (no checkpoint offline)",
+                       "backend": "inline" if pipe.worker is None else "own host thread + stream (as the reference's backend process)",
                        "frontend": "eager launches" + (", HIP graphs" if args.graphs else "") +
                                    ("" if args.no_pipeline else ", encoder of frame f+1 overlapped with frame f on a second stream"),
                        "parallelism": f"streams x{world}, GN edges + TSDF voxels sharded"},

@@ -71,10 +71,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
   static_assert(N_DMA * (S - 1) < 64, "vmcnt range");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [S][BM + BN][128 B]
 
-  // XCD-aware tile order: blocks sharing an XCD get neighbouring tiles (same A rows / W panel in L2)
+  // Tile order.  (1) xcd_remap: the blocks the dispatcher deals to one XCD get a contiguous range of
+  // logical ids.  (2) Inside that order tiles are walked in groups of GM row-panels (~1024 rows),
+  // column-major inside a group: the blocks that run together on an XCD then share a few A panels AND
+  // a few W panels, so every W panel crosses the fabric into that XCD's L2 once per group instead of
+  // once per row-panel; for the small-M shapes (all rows in one group) each XCD reads only its own
+  // slice of W.
   const unsigned nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   const unsigned tile = xcd_remap(blockIdx.x, nbm * nbn);
-  const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+  constexpr unsigned GM = 1024 / BM;
+  const unsigned per_group = GM * nbn, grp = tile / per_group, in_grp = tile - grp * per_group;
+  const unsigned gsz = min(nbm - grp * GM, GM);
+  const int m0 = (grp * GM + in_grp % gsz) * BM, n0 = (in_grp / gsz) * BN;
 
   const int t = threadIdx.x, lane = t & 63;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);

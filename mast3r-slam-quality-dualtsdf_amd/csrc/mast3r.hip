@@ -12,6 +12,8 @@
 // 24x32 token grid), DPT feature maps NHWC bf16.  The 1x1 out_conv of each fusion block is applied
 // BEFORE the bilinear x2 upsample (both are linear and commute; 4x fewer FLOPs).
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <vector>
 #include "common.h"
 #include "gemm.h"
@@ -264,9 +266,32 @@ struct Mast3rModel {
   float* rope_sin = nullptr;
   int rope_len = 0;
   int hooks[4];
-  hipStream_t side_stream = nullptr;   // second queue: decoder side 2 / head 2 run beside side 1 / head 1
-  std::vector<hipEvent_t> events;      // fork/join events, cycled
-  mutable size_t ev_next = 0;
+  // Second queue of a decode call (decoder side 2 / head 2 run beside side 1 / head 1) with its fork/join
+  // events.  One per CALLER stream, created on first use: decode calls issued on different streams (the
+  // frontend and the backend of the SLAM system run concurrently) never share a queue or an event.
+  struct Fork {
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> events;
+    size_t ev_next = 0;
+  };
+  bool two_streams = true;
+  mutable std::mutex fork_mu;
+  mutable std::map<hipStream_t, Fork*> forks;
+  Fork* fork_for(hipStream_t caller, int& rc) const {
+    std::lock_guard<std::mutex> lock(fork_mu);
+    auto it = forks.find(caller);
+    if (it != forks.end()) return it->second;
+    Fork* f = new Fork();
+    rc = check_hip(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking), "side stream");
+    for (int k = 0; k < 64 && !rc; k++) {
+      hipEvent_t ev;
+      rc = check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "event");
+      if (!rc) f->events.push_back(ev);
+    }
+    if (rc) { delete f; return nullptr; }
+    forks[caller] = f;
+    return f;
+  }
 };
 
 struct PtrFeed {
@@ -313,6 +338,7 @@ struct Ctx {
   Arena ar;
   hipStream_t s;
   int rc = MSLAM_OK;
+  Mast3rModel::Fork* fk = nullptr;
   bool dry() const { return ar.dry; }
   void fail(int r) { if (rc == MSLAM_OK) rc = r; }
 };
@@ -566,8 +592,7 @@ static void dec_block(Ctx& c, const DecBlock& b, float* x, const bf16* yn, int B
 // fork/join between the caller's stream and the model's side stream (no-ops in the sizing pass)
 static void stream_wait(Ctx& c, hipStream_t waiter, hipStream_t on) {
   if (c.dry() || c.rc) return;
-  const Mast3rModel& m = *c.m;
-  hipEvent_t ev = m.events[m.ev_next++ % m.events.size()];
+  hipEvent_t ev = c.fk->events[c.fk->ev_next++ % c.fk->events.size()];
   c.fail(check_hip(hipEventRecord(ev, on), "hipEventRecord"));
   c.fail(check_hip(hipStreamWaitEvent(waiter, ev, 0), "hipStreamWaitEvent"));
 }
@@ -582,7 +607,12 @@ static void decode(Ctx& c, const float* feat1, const float* feat2, int B, int H,
   const int nh = H / m.P, nw = W / m.P, N = nh * nw, M = B * N;
   const float* feat[2] = {feat1, feat2};
   float* dec_last[2] = {dec_last1, dec_last2};
-  hipStream_t sA = c.s, sB = (c.dry() || !m.side_stream) ? c.s : m.side_stream;
+  if (!c.dry() && m.two_streams && !c.rc) {
+    int frc = MSLAM_OK;
+    c.fk = m.fork_for(c.s, frc);
+    c.fail(frc);
+  }
+  hipStream_t sA = c.s, sB = c.fk ? c.fk->side : c.s;
   hipStream_t st[2] = {sA, sB};
   bf16* fb[2];
   float* x[2];
@@ -714,14 +744,7 @@ extern "C" int mslam_mast3r_create(void** handle_out, const int* cfg9, void* con
   if (!rc) rc = check_hip(hipMemcpyAsync(m->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream), "rope copy");
   if (!rc) rc = check_hip(hipMemcpyAsync(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream), "rope copy");
   if (!rc) rc = check_hip(hipStreamSynchronize((hipStream_t)stream), "rope sync");
-  if (!rc && !getenv("MSLAM_SINGLE_STREAM")) {
-    rc = check_hip(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking), "side stream");
-    for (int k = 0; k < 64 && !rc; k++) {
-      hipEvent_t ev;
-      rc = check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "event");
-      if (!rc) m->events.push_back(ev);
-    }
-  }
+  m->two_streams = getenv("MSLAM_SINGLE_STREAM") == nullptr;
   if (rc) { delete m; return rc; }
   *handle_out = m;
   return MSLAM_OK;
@@ -732,8 +755,11 @@ extern "C" int mslam_mast3r_destroy(void* handle) {
   if (!m) return MSLAM_OK;
   if (m->rope_cos) (void)hipFree(m->rope_cos);
   if (m->rope_sin) (void)hipFree(m->rope_sin);
-  for (hipEvent_t ev : m->events) (void)hipEventDestroy(ev);
-  if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+  for (auto& kv : m->forks) {
+    for (hipEvent_t ev : kv.second->events) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(kv.second->side);
+    delete kv.second;
+  }
   delete m;
   return MSLAM_OK;
 }

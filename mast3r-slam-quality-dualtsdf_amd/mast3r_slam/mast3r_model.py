@@ -148,16 +148,17 @@ class Mast3rHIP:
         return self
 
     def _workspace(self, B, H, W, kind="dec"):
-        """Arena for one call; encode and decode keep separate arenas so that the encoder of the next frame
-        may run on another stream while the current frame is decoded."""
+        """Arena for one call, one per (kind, calling stream): the encoder of the next frame and the
+        backend's batched decode may run on other streams while the current frame is decoded."""
         need = _m.lib().mslam_mast3r_workspace_bytes(self._h, B, H, W)
         if need == 0:
             _m.check(-1, "mast3r_workspace_bytes")
         if self._ws is None:
             self._ws = {}
-        if kind not in self._ws or self._ws[kind].numel() < need:
-            self._ws[kind] = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws[kind]
+        key = (kind, _m.stream_ptr())
+        if key not in self._ws or self._ws[key].numel() < need:
+            self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws[key]
 
     def positions(self, B, H, W):
         """PositionGetter (croco/models/blocks.py:195-207): (B, N, 2) int64 [y, x]."""
@@ -224,7 +225,7 @@ class Mast3rHIP:
                 run()
             torch.cuda.current_stream(self.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):   # other host threads keep launching
                 run()
             ent = self._graphs[key] = (g, static_in, outs, ws)
         g, static_in, outs, _ = ent
