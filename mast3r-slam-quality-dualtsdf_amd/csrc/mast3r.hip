@@ -119,6 +119,56 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
   }
 }
 
+// Two LayerNorms of the SAME rows with different affine parameters (decoder: norm_y of one side and norm1
+// of the other both normalise the previous layer's tokens): statistics once, two bf16 outputs.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_dual_vec_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                                 const float* __restrict__ b1, bf16* __restrict__ out1,
+                                                                 const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                 bf16* __restrict__ out2, int rows, float eps) {
+  constexpr int D = NV * 256;
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  float4 v[NV];
+#pragma unroll
+  for (int c = 0; c < NV; c++) v[c] = xr[lane + 64 * c];
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NV; c++) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float mean = s / (float)D;
+  float q = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NV; c++) {
+    const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
+    q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+  const float rstd = rsqrtf(q / (float)D + eps);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const float* w = k ? w2 : w1;
+    const float* b = k ? b2 : b1;
+    bf16* out = k ? out2 : out1;
+#pragma unroll
+    for (int c = 0; c < NV; c++) {
+      const float4 wv = reinterpret_cast<const float4*>(w)[lane + 64 * c];
+      const float4 bv = reinterpret_cast<const float4*>(b)[lane + 64 * c];
+      bf16x4 o;
+      o[0] = (bf16)((v[c].x - mean) * rstd * wv.x + bv.x);
+      o[1] = (bf16)((v[c].y - mean) * rstd * wv.y + bv.y);
+      o[2] = (bf16)((v[c].z - mean) * rstd * wv.z + bv.z);
+      o[3] = (bf16)((v[c].w - mean) * rstd * wv.w + bv.w);
+      reinterpret_cast<bf16x4*>(out + (size_t)row * D)[lane + 64 * c] = o;
+    }
+  }
+}
+
 static void launch_layernorm(const float* x, const float* w, const float* b, bf16* out_bf, float* out_f, int rows, int D,
                              float eps, hipStream_t s) {
   const dim3 grid((rows + 3) / 4), block(256);
@@ -241,7 +291,7 @@ struct Lin { const bf16* W; const float* b; int out, in; };
 struct Norm { const float* w; const float* b; int d; };
 
 struct EncBlock { Norm n1; Lin qkv, proj; Norm n2; Lin fc1, fc2; };
-struct DecBlock { Norm n1; Lin qkv, proj; Norm n2, ny; Lin pq, pk, pv, cproj; Norm n3; Lin fc1, fc2; };
+struct DecBlock { Norm n1; Lin qkv, proj; Norm n2, ny; Lin pq, pkv, cproj; Norm n3; Lin fc1, fc2; };
 struct Rcu { Lin c1, c2; };
 struct Fusion { Rcu r1, r2; Lin out; bool has_r1; };
 struct Head {
@@ -339,6 +389,7 @@ struct Ctx {
   hipStream_t s;
   int rc = MSLAM_OK;
   Mast3rModel::Fork* fk = nullptr;
+  int side = 0;   // which queue of the call c.s currently is
   bool dry() const { return ar.dry; }
   void fail(int r) { if (rc == MSLAM_OK) rc = r; }
 };
@@ -370,6 +421,20 @@ static void layernorm(Ctx& c, const float* x, const Norm& n, int rows, bf16* out
   if (c.dry() || c.rc) return;
   launch_layernorm(x, n.w, n.b, out_bf, out_f, rows, n.d, 1e-6f, c.s);
   dbg(c, "layernorm", rows, n.d);
+}
+
+static void layernorm2(Ctx& c, const float* x, const Norm& n1, bf16* out1, const Norm& n2, bf16* out2, int rows) {
+  if (c.dry() || c.rc) return;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (n1.d == 768 && n2.d == 768)
+    hipLaunchKernelGGL(layernorm_dual_vec_kernel<3>, grid, block, 0, c.s, x, n1.w, n1.b, out1, n2.w, n2.b, out2, rows, 1e-6f);
+  else if (n1.d == 1024 && n2.d == 1024)
+    hipLaunchKernelGGL(layernorm_dual_vec_kernel<4>, grid, block, 0, c.s, x, n1.w, n1.b, out1, n2.w, n2.b, out2, rows, 1e-6f);
+  else {
+    launch_layernorm(x, n1.w, n1.b, out1, nullptr, rows, n1.d, 1e-6f, c.s);
+    launch_layernorm(x, n2.w, n2.b, out2, nullptr, rows, n2.d, 1e-6f, c.s);
+  }
+  dbg(c, "layernorm2", rows, n1.d);
 }
 
 static void cast_bf16(Ctx& c, const float* x, bf16* y, size_t n) {
@@ -575,14 +640,13 @@ static void dec_block(Ctx& c, const DecBlock& b, float* x, const bf16* yn, int B
                       BlockScratch& s) {
   const Mast3rModel& m = *c.m;
   const int M = B * N, Mk = B * Nk;
-  layernorm(c, x, b.n1, M, s.h, nullptr);
+  // s.h already holds norm1(x): computed together with the other side's norm_y (layernorm2 in decode())
   attn_project(c, s.h, M, b.qkv, 0, m.dec_heads, N, N, nw, s.ab);
   attention(c, s.ab, B, m.dec_heads, N, N);
   linear_residual(c, s.ab.o, M, b.proj, x);
   layernorm(c, x, b.n2, M, s.h, nullptr);
   attn_project(c, s.h, M, b.pq, 0, m.dec_heads, N, Nk, nw, s.ab);
-  attn_project(c, yn, Mk, b.pk, 1, m.dec_heads, N, Nk, nw_k, s.ab);
-  attn_project(c, yn, Mk, b.pv, 2, m.dec_heads, N, Nk, nw_k, s.ab);
+  attn_project(c, yn, Mk, b.pkv, 1, m.dec_heads, N, Nk, nw_k, s.ab);   // [projk; projv] stacked: sections 1 and 2
   attention(c, s.ab, B, m.dec_heads, N, Nk);
   linear_residual(c, s.ab.o, M, b.cproj, x);
   mlp_residual(c, x, M, b.n3, b.fc1, b.fc2, s);
@@ -629,18 +693,18 @@ static void decode(Ctx& c, const float* feat1, const float* feat2, int B, int H,
   }
   if (sB != sA) stream_wait(c, sB, sA);  // fork: side stream starts after everything already queued
   for (int s = 0; s < 2; s++) {
-    c.s = st[s];
+    c.s = st[s]; c.side = s;
     cast_bf16(c, feat[s], fb[s], (size_t)M * m.E);
     linear_f32(c, fb[s], M, m.dec_embed, x[s]);
   }
   for (int l = 0; l < m.dec_depth; l++) {
-    c.s = sA;
+    c.s = sA; c.side = 0;
     if (sB != sA) stream_wait(c, sA, sB);                     // x[1] of the previous layer is final
-    layernorm(c, x[1], m.dec[0][l].ny, M, yn[0], nullptr);    // memory for side 1 = norm_y(f2)
-    layernorm(c, x[0], m.dec[1][l].ny, M, yn[1], nullptr);    // memory for side 2 = norm_y(f1)
+    layernorm2(c, x[1], m.dec[0][l].ny, yn[0], m.dec[1][l].n1, bs[1].h, M);   // memory for side 1 = norm_y(f2); side 2's norm1
+    layernorm2(c, x[0], m.dec[1][l].ny, yn[1], m.dec[0][l].n1, bs[0].h, M);   // memory for side 2 = norm_y(f1); side 1's norm1
     if (sB != sA) stream_wait(c, sB, sA);                     // memories ready; x[0] final for side 2's reads
     for (int s = 0; s < 2; s++) {
-      c.s = st[s];
+      c.s = st[s]; c.side = s; c.side = s;
       dec_block(c, m.dec[s][l], x[s], yn[s], B, N, N, nw, nw, bs[s]);
       for (int k = 1; k < 3; k++)
         if (l + 1 == m.hooks[k]) cast_bf16(c, x[s], tok[s][k], (size_t)M * m.Dd);
@@ -649,14 +713,14 @@ static void decode(Ctx& c, const float* feat1, const float* feat2, int B, int H,
   const size_t mark = c.ar.off;
   size_t end = mark;
   for (int s = 0; s < 2; s++) {
-    c.s = st[s];
+    c.s = st[s]; c.side = s;
     layernorm(c, x[s], m.dec_norm, M, tok[s][3], dec_last[s]);
     // each head gets its own scratch region when the two run concurrently
     c.ar.off = (sB != sA || c.dry()) ? end : mark;
     run_head(c, m.head[s], tok[s], B, H, W, out[s]);
     end = c.ar.off;
   }
-  c.s = sA;
+  c.s = sA; c.side = 0;
   if (sB != sA) stream_wait(c, sA, sB);  // join
 }
 
@@ -694,7 +758,7 @@ extern "C" int mslam_mast3r_create(void** handle_out, const int* cfg9, void* con
       DecBlock b;
       b.n1 = f.norm(D, "dec.norm1"); b.qkv = f.lin(3 * D, D, true, "dec.qkv"); b.proj = f.lin(D, D, true, "dec.proj");
       b.n2 = f.norm(D, "dec.norm2"); b.ny = f.norm(D, "dec.norm_y");
-      b.pq = f.lin(D, D, true, "dec.projq"); b.pk = f.lin(D, D, true, "dec.projk"); b.pv = f.lin(D, D, true, "dec.projv");
+      b.pq = f.lin(D, D, true, "dec.projq"); b.pkv = f.lin(2 * D, D, true, "dec.projkv");
       b.cproj = f.lin(D, D, true, "dec.cross_proj");
       b.n3 = f.norm(D, "dec.norm3"); b.fc1 = f.lin(4 * D, D, true, "dec.fc1"); b.fc2 = f.lin(D, 4 * D, true, "dec.fc2");
       m->dec[s].push_back(b);

@@ -83,8 +83,13 @@ def canonical_weights(sd, cfg, device):
             p = f"{blocks}.{i}"
             norm(p + ".norm1"); lin(p + ".attn.qkv"); lin(p + ".attn.proj")
             norm(p + ".norm2"); norm(p + ".norm_y")
-            for q in ("projq", "projk", "projv", "proj"):
-                lin(f"{p}.cross_attn.{q}")
+            lin(f"{p}.cross_attn.projq")
+            # projk and projv read the same memory tokens: one [2D, D] matrix, one launch
+            wk, wv = get(f"{p}.cross_attn.projk.weight").float(), get(f"{p}.cross_attn.projv.weight").float()
+            out.append(torch.cat((wk, wv), 0).to(device=device, dtype=torch.bfloat16).contiguous())
+            out.append(torch.cat((get(f"{p}.cross_attn.projk.bias"), get(f"{p}.cross_attn.projv.bias")), 0)
+                       .to(device=device, dtype=torch.float32).contiguous())
+            lin(f"{p}.cross_attn.proj")
             norm(p + ".norm3"); lin(p + ".mlp.fc1"); lin(p + ".mlp.fc2")
     norm("dec_norm")
     for h in (1, 2):
