@@ -7,6 +7,7 @@ namespace mslam {
 
 int launch_gemm_t64(const GemmArgs& a, int stages, hipStream_t s);
 int launch_gemm_t128(const GemmArgs& a, int waves, int stages, hipStream_t s);
+int launch_gemm_t128x64(const GemmArgs& a, int stages, hipStream_t s);
 int launch_gemm_t256(const GemmArgs& a, int bn, hipStream_t s);
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
@@ -25,7 +26,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   // (or many waves) per CU: shallow rings, 32-64 KiB of LDS per 4 waves.  Larger tiles halve the L2->LDS
   // traffic and win as soon as they still cover the chip.
   // MSLAM_GEMM="<cfg>" forces one configuration for experiments:
-  //   642/643/644: 64x64 ring 2/3/4; 1242: 128x128 4 waves; 1282/1283: 128x128 8 waves ring 2/3;
+  //   642/643/644: 64x64 ring 2/3/4; 1262/1263: 128x64 ring 2/3; 1242: 128x128 4 waves; 1282/1283: 128x128 8 waves ring 2/3;
   //   2128: 256x128 8 waves; 2256: 256x256 16 waves
   static int forced = -2;
   if (forced == -2) {
@@ -47,6 +48,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     case 642: return launch_gemm_t64(a, 2, stream);
     case 643: return launch_gemm_t64(a, 3, stream);
     case 644: return launch_gemm_t64(a, 4, stream);
+    case 1262: return launch_gemm_t128x64(a, 2, stream);
+    case 1263: return launch_gemm_t128x64(a, 3, stream);
     case 1242: return launch_gemm_t128(a, 4, 2, stream);
     case 1282: return launch_gemm_t128(a, 8, 2, stream);
     case 1283: return launch_gemm_t128(a, 8, 3, stream);

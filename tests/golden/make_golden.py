@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tsdf_global  tsdf_refine  network
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -306,6 +306,44 @@ def section_tsdf_refine():
 
 
 SECTIONS["tsdf_refine"] = section_tsdf_refine
+
+
+def section_resize():
+    """a1: resize_img (mast3r_utils.py:236-278).  The module itself cannot be imported (torchvision, cv2,
+    the retrieval stack); its two PIL functions are taken from the reference file's AST and executed with
+    ImgNorm restated in numpy (dust3r/utils/image.py:23: ToTensor + Normalize(0.5, 0.5))."""
+    import ast
+
+    import PIL.Image
+
+    path = os.path.join(REF, "mast3r_slam/mast3r_utils.py")
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("_resize_pil_image", "resize_img")]
+    assert len(keep) == 2
+    ns = {"PIL": PIL, "np": np,
+          "ImgNorm": lambda im: torch.from_numpy(((np.asarray(im, np.float32) / 255.0 - 0.5) / 0.5).transpose(2, 0, 1).copy())}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    rng = np.random.default_rng(7)
+    out = {}
+    # inputs are stored as uint8 (the function quantises to uint8 first: np.uint8(img * 255)); the float image
+    # handed to both implementations is (u8 + 0.5) / 255, which truncates back to u8 exactly.  Outputs: the
+    # uint8 crop; `img` is its ImgNorm and is checked against that formula in the test.
+    for name, (h, w) in {"lanczos": (530, 700), "bicubic": (200, 320), "square": (300, 300)}.items():
+        u8 = rng.integers(0, 256, (h // 4 + 1, w // 4 + 1, 3)).astype(np.uint8)
+        u8 = np.repeat(np.repeat(u8, 4, 0), 4, 1)[:h, :w]          # 4x4 blocks: structure for the filters, compressible
+        img = ((u8.astype(np.float32) + 0.5) / 255.0).astype(np.float32)
+        assert np.array_equal(np.uint8(img * 255), u8)
+        res, tf = ns["resize_img"](img, 512, return_transformation=True)
+        out[f"{name}_in_u8"] = u8
+        out[f"{name}_true_shape"] = res["true_shape"]
+        out[f"{name}_uimg"] = res["unnormalized_img"]
+        out[f"{name}_img_sum"] = np.float64(res["img"].double().sum().item())
+        out[f"{name}_tf"] = np.array(tf, np.float64)
+    np.savez_compressed(os.path.join(HERE, "resize_img.npz"), **out, **meta())
+    print("resize:", {k: v.shape for k, v in out.items() if k.endswith("_uimg")})
+
+
+SECTIONS["resize"] = section_resize
 
 
 if __name__ == "__main__":
