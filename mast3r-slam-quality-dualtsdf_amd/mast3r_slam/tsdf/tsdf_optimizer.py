@@ -22,6 +22,35 @@ class TSDFPoseOptimizer:
         self.pre_icp_iters = int(cfg.get("pre_icp_iters", 0))
         self._ws = torch.empty(64 * 36 * 8, dtype=torch.uint8, device=volume.device)
 
+    # ------------------------------------------------------------------ reference method surface
+    def pre_refine(self, kf_idx):
+        """tsdf_optimizer.py:29-37."""
+        if self.pre_icp_iters <= 0:
+            return
+        self._optimize_single(kf_idx, iterations=self.pre_icp_iters, sample_override=min(self.samples_per_kf // 2, 1000))
+
+    def optimize_keyframes(self, indices, context="factor"):
+        """tsdf_optimizer.py:39-43."""
+        for idx in indices or ():
+            self._optimize_single(idx, iterations=self.max_iterations)
+
+    def _optimize_single(self, idx, iterations, sample_override=0, log_prefix="[TSDF]"):
+        """tsdf_optimizer.py:46-92: sample <= samples_per_kf points with C > min_confidence (torch.randperm,
+        as the reference), iterate pose <- exp(delta) * pose against the volume, write T_WC back."""
+        if idx >= len(self.keyframes):
+            return
+        frame = self.keyframes[idx]
+        points = frame.X_canon.detach().reshape(-1, 3)
+        conf = frame.C.detach().reshape(-1)
+        valid_idx = torch.nonzero(conf > self.min_conf).view(-1)
+        if valid_idx.numel() == 0:
+            return
+        max_samples = sample_override if sample_override > 0 else self.samples_per_kf
+        count = min(max_samples, valid_idx.numel())
+        choice = valid_idx[torch.randperm(valid_idx.numel(), device=valid_idx.device)[:count]]
+        pose = self.refine_pose(Sim3(frame.T_WC.data.clone()), points[choice], conf[choice], iterations=iterations)
+        frame.T_WC = pose
+
     def normal_equations(self, points_world, conf):
         """_build_linear_system + _accumulate_system (tsdf_optimizer.py:94-116) for world points:
         returns (H f64[7,7], b f64[7], used i32) device tensors."""
