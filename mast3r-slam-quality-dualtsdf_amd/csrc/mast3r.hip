@@ -246,9 +246,89 @@ __global__ void upsample2x_kernel(const bf16* __restrict__ in, bf16* __restrict_
   *reinterpret_cast<bf16x8*>(out + pix * C + cc) = o;
 }
 
-// Final 1x1 conv (128 -> 4) + pixel_shuffle(16) of the local-feature MLP + postprocess
-// (catmlp_dpt_head.py:25-39, postprocess.py:22-58): one thread per pixel, all fp32.
+// Final 1x1 conv (fc -> 4) + pixel_shuffle(P) of the local-feature MLP + postprocess
+// (catmlp_dpt_head.py:25-39, postprocess.py:22-58), all fp32.  One block per token = P x P pixel patch
+// (P = 16, 256 threads): every global access is a full-line one.
+//   phase 1: the patch's feature rows (16 px x fc bf16 = 4 KiB contiguous per image row) are read 16 B per
+//            lane; the 16 lanes that share a pixel reduce their partial dot products with shuffles
+//   phase 2: thread = pixel: reads its 25 local-feature values (contiguous across the patch per channel),
+//            normalises, and the four outputs leave through LDS row buffers as 16-byte stores.
+constexpr int kHP = 16;   // patch size the kernel is built for
 __global__ __launch_bounds__(256) void head_post_kernel(const bf16* __restrict__ feat, int fc,
+                                                        const float* __restrict__ w4, const float* __restrict__ b4,
+                                                        const float* __restrict__ lf, int lf_ld, int desc_dim,
+                                                        int B, int H, int W, float* __restrict__ X,
+                                                        float* __restrict__ Cf, float* __restrict__ D,
+                                                        float* __restrict__ Q) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+  __shared__ float l_s[kHP * kHP][4];
+  __shared__ __attribute__((aligned(16))) float d_s[kHP * kHP * 24];   // [row][px][desc] = the patch rows of D
+  __shared__ __attribute__((aligned(16))) float x_s[kHP * kHP * 3];
+  const int t = threadIdx.x;
+  const int nw = W / kHP, nh = H / kHP;
+  const int tok = blockIdx.x;                       // b * nh * nw + ty * nw + tx
+  const int b = tok / (nh * nw), ty = (tok / nw) % nh, tx = tok % nw;
+  const size_t pix00 = ((size_t)b * H + (size_t)ty * kHP) * W + (size_t)tx * kHP;   // top-left pixel of the patch
+  // ---- phase 1: 1x1 conv, fc = 128: 16 lanes x 8 channels per pixel --------------------------------
+  const int cg = t & 15, ppx = t >> 4;              // channel group, pixel within the patch row
+  float wr[4][8];
+#pragma unroll
+  for (int o = 0; o < 4; o++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) wr[o][k] = w4[o * fc + cg * 8 + k];
+  for (int r = 0; r < kHP; r++) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(feat + (pix00 + (size_t)r * W + ppx) * fc + cg * 8);
+    float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float fv = (float)v[k];
+#pragma unroll
+      for (int o = 0; o < 4; o++) p[o] = fmaf(wr[o][k], fv, p[o]);
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+      for (int o = 0; o < 4; o++) p[o] += __shfl_xor(p[o], off, 64);
+    if (cg == 0) {
+#pragma unroll
+      for (int o = 0; o < 4; o++) l_s[r * kHP + ppx][o] = p[o] + b4[o];
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: thread = pixel (py, px) of the patch ----------------------------------------------------
+  const int py = t >> 4, px = t & 15;
+  const float l0 = l_s[t][0], l1 = l_s[t][1], l2 = l_s[t][2], l3 = l_s[t][3];
+  const float d = sqrtf(l0 * l0 + l1 * l1 + l2 * l2);
+  const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+  x_s[t * 3 + 0] = l0 * sc; x_s[t * 3 + 1] = l1 * sc; x_s[t * 3 + 2] = l2 * sc;
+  const size_t pix = pix00 + (size_t)py * W + px;
+  Cf[pix] = 1.0f + expf(l3);                                    // 16 consecutive floats per patch row
+  const float* lp = lf + (size_t)tok * lf_ld + t;               // channel c of this pixel: lp[c * 256]
+  float dv[24];
+  float nn = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 24; c++) { dv[c] = lp[c * kHP * kHP]; nn = fmaf(dv[c], dv[c], nn); }
+  const float inv = 1.0f / sqrtf(nn);
+#pragma unroll
+  for (int c = 0; c < 24; c++) d_s[t * 24 + c] = dv[c] * inv;
+  Q[pix] = expf(lp[24 * kHP * kHP]);
+  __syncthreads();
+  // patch row r of D = 16 px x 24 floats = 96 float4, contiguous in memory; 16 rows -> 1536 float4 / 256 threads
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const int e = t + 256 * k, r = e / 96, q = e - r * 96;
+    *reinterpret_cast<float4*>(D + (pix00 + (size_t)r * W) * 24 + q * 4) = *reinterpret_cast<const float4*>(d_s + r * 384 + q * 4);
+  }
+  if (t < 192) {   // X: 16 rows x 12 float4
+    const int r = t / 12, q = t - r * 12;
+    *reinterpret_cast<float4*>(X + (pix00 + (size_t)r * W) * 3 + q * 4) = *reinterpret_cast<const float4*>(x_s + r * 48 + q * 4);
+  }
+}
+
+// Generic form (any patch size / channel count), one thread per pixel: used when the shape is not the
+// production one the patch kernel above is built for.
+// (catmlp_dpt_head.py:25-39, postprocess.py:22-58): one thread per pixel, all fp32.
+__global__ __launch_bounds__(256) void head_post_generic_kernel(const bf16* __restrict__ feat, int fc,
                                                         const float* __restrict__ w4, const float* __restrict__ b4,
                                                         const float* __restrict__ lf, int lf_ld, int desc_dim, int P,
                                                         int B, int H, int W, float* __restrict__ X,
@@ -629,9 +709,14 @@ static void run_head(Ctx& c, const Head& hd, const bf16* const toks[4], int B, i
   linear_bf16(c, cat, M, hd.fc1, hid, ACT_GELU);
   linear_f32(c, hid, M, hd.fc2, lf);
   if (!c.dry() && !c.rc) {
-    const size_t npix = (size_t)B * H * W;
-    hipLaunchKernelGGL(head_post_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c.s, h2, hd.h2.out, hd.h4w,
-                       hd.h4b, lf, hd.fc2.out, m.desc_dim, m.P, B, H, W, out.X, out.C, out.D, out.Q);
+    if (m.P == kHP && hd.h2.out == 128 && m.desc_dim == 24) {
+      hipLaunchKernelGGL(head_post_kernel, dim3((unsigned)(B * (H / m.P) * (W / m.P))), dim3(256), 0, c.s, h2, hd.h2.out,
+                         hd.h4w, hd.h4b, lf, hd.fc2.out, m.desc_dim, B, H, W, out.X, out.C, out.D, out.Q);
+    } else {
+      const size_t npix = (size_t)B * H * W;
+      hipLaunchKernelGGL(head_post_generic_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c.s, h2, hd.h2.out,
+                         hd.h4w, hd.h4b, lf, hd.fc2.out, m.desc_dim, m.P, B, H, W, out.X, out.C, out.D, out.Q);
+    }
     dbg(c, "head_post", B, H, W);
   }
 }
