@@ -45,6 +45,14 @@ struct GemmArgs {
   float q_scale;
   // EPI_CONVT
   int ct_s, ct_cout, ct_h, ct_w;
+  // Grouped launch (groups == 2): a second, independent problem of the SAME shape runs in the same grid
+  // (the two sides of a decoder layer).  Activations of the second problem sit at fixed strides behind the
+  // first one's; its weights and bias are separate allocations.
+  int groups;                    // 0 / 1 = single problem
+  const bf16* W1; const float* bias1;
+  size_t a_gstride;              // elements of A
+  size_t out_gbytes, res1_gbytes, res2_gbytes;   // bytes (the kinds differ)
+  size_t qkv_gstride;            // elements of q_out / k_out / vt_out
 };
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);

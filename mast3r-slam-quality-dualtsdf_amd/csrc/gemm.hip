@@ -33,7 +33,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     const char* e = getenv("MSLAM_GEMM");
     forced = e ? atoi(e) : -1;
   }
-  auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  MSLAM_REQUIRE(a.groups <= 2 && (a.groups < 2 || (a.W1 && !a.a_conv)), "gemm: bad group description");
+  const long ngrp = a.groups > 1 ? 2 : 1;
+  auto blocks = [&](int bm, int bn) { return ngrp * ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int cfg = forced;
   if (cfg < 0) {
     const bool narrow = a.N <= 128 || (a.N > 256 && a.N <= 384);   // a 256-wide tile would be >= 25 % padding

@@ -78,7 +78,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
   // once per row-panel; for the small-M shapes (all rows in one group) each XCD reads only its own
   // slice of W.
   const unsigned nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
-  const unsigned tile = xcd_remap(blockIdx.x, nbm * nbn);
+  const unsigned ngrp = g.groups > 1 ? 2u : 1u;
+  const unsigned logical = xcd_remap(blockIdx.x, nbm * nbn * ngrp);   // group 0 on the first XCDs, group 1 on the rest
+  const unsigned prob = logical / (nbm * nbn), tile = logical - prob * (nbm * nbn);
+  if (prob) {   // second problem of a grouped launch (block-uniform)
+    g.A += g.a_gstride; g.W = g.W1; g.bias = g.bias1;
+    g.out = reinterpret_cast<char*>(g.out) + g.out_gbytes;
+    if (g.res1) g.res1 = reinterpret_cast<const char*>(g.res1) + g.res1_gbytes;
+    if (g.res2) g.res2 = reinterpret_cast<const char*>(g.res2) + g.res2_gbytes;
+    if (g.epi == EPI_ATTN) { g.q_out += g.qkv_gstride; g.k_out += g.qkv_gstride; g.vt_out += g.qkv_gstride; }
+  }
   constexpr unsigned GM = 1024 / BM;
   const unsigned per_group = GM * nbn, grp = tile / per_group, in_grp = tile - grp * per_group;
   const unsigned gsz = min(nbm - grp * GM, GM);
@@ -451,7 +460,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr size_t ring = (size_t)S * (BM + BN) * 128, patch = (size_t)NW * 32 * 40 * sizeof(float);
   constexpr size_t shmem = ring > patch ? ring : patch;
   static_assert(shmem <= 160 * 1024, "LDS budget");
-  const unsigned blocks = (unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN));
+  const unsigned blocks = (unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)) * (a.groups > 1 ? 2u : 1u);
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
   if (!attr_set) {
     const void* fns[2] = {(const void*)gemm_bf16_kernel<WM, WN, MI, NI, S, false>,
