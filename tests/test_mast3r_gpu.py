@@ -151,3 +151,44 @@ def test_graph_replay_matches_eager(device):
         kept.append((rg1["pts3d"], re1["pts3d"].clone()))
     for got, want in kept:   # earlier results were not overwritten by later replays
         assert torch.equal(got, want)
+
+
+def test_concurrent_calls_from_two_threads(device):
+    """The SLAM frontend and backend call the model at the same time from different host threads and streams
+    (bench.py): every (call kind, stream) has its own arena and fork context, so concurrent results are
+    bit-identical to the same calls issued one after the other."""
+    import threading
+
+    from mast3r_slam.mast3r_model import Mast3rConfig, Mast3rHIP
+
+    cfg = R.Mast3rConfig(enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=12, dec_heads=2)
+    sd = R.init_state_dict(cfg, seed=21)
+    model = Mast3rHIP(sd, Mast3rConfig(cfg.enc_dim, cfg.enc_depth, cfg.enc_heads, cfg.dec_dim, cfg.dec_depth, cfg.dec_heads),
+                      device=device)
+    g = torch.Generator().manual_seed(9)
+    H, W = 64, 96
+    img_a = (torch.rand(1, 3, H, W, generator=g) * 2 - 1).to(device)
+    img_b = (torch.rand(3, 3, H, W, generator=g) * 2 - 1).to(device)
+
+    def work(img):
+        f = model._encode_image(img)[0]
+        r1, r2 = model.decode_pair(f, f.flip(0), H, W)
+        return f, r1["pts3d"], r2["desc"]
+
+    want_a, want_b = work(img_a), work(img_b)
+    torch.cuda.synchronize()
+    got = {}
+
+    def runner(name, img, reps):
+        with torch.cuda.stream(torch.cuda.Stream(device=device)):
+            for _ in range(reps):
+                got[name] = work(img)
+            torch.cuda.current_stream().synchronize()
+
+    ta = threading.Thread(target=runner, args=("a", img_a, 6))
+    tb = threading.Thread(target=runner, args=("b", img_b, 3))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    for w_, g_ in zip(want_a, got["a"]):
+        assert torch.equal(w_, g_)
+    for w_, g_ in zip(want_b, got["b"]):
+        assert torch.equal(w_, g_)
