@@ -98,6 +98,7 @@ class BackendWorker(threading.Thread):
         self.start()
 
     def run(self):
+        torch.cuda.set_device(self.dev)   # the current device is per host thread
         stream = torch.cuda.Stream(device=self.dev)
         with torch.cuda.stream(stream):
             while True:
@@ -193,8 +194,9 @@ class Pipeline:
             m[y0:y0 + 32, x0:x0 + 32] = True
             self.refine_blocks.append(PatchBlock(0, b, m.reshape(-1)))
         # frontend pipeline: the encoder of frame f+1 runs on its own stream beside decode/match/track of frame f
-        # multi-GPU: the backend issues collectives, keep them on the thread that owns the process group
-        self.worker = None if (args.no_backend_thread or world > 1) else BackendWorker(dev)
+        # multi-GPU: the backend thread is the only issuer of collectives while the clock runs (same order on every
+        # rank); the main thread's barrier / all-reduce come after drain()
+        self.worker = None if args.no_backend_thread else BackendWorker(dev)
         self.enc_stream = torch.cuda.Stream(device=dev)
         self.next_feat, self.enc_done = None, None
         self.net_ms = 0.0
