@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--edges-per-kf", type=int, default=4)
     ap.add_argument("--graph-kfs", type=int, default=8, help="keyframes in the backend graph PER GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="debug: all ranks on cuda:0 with gloo collectives (rehearses the N>1 code path on a one-GPU box)")
     ap.add_argument("--graphs", action="store_true", help="replay the network as captured HIP graphs (default: eager)")
     ap.add_argument("--no-backend-thread", action="store_true",
                     help="run the keyframe backend inline in the tracking loop instead of on its own thread + stream")
@@ -70,8 +72,13 @@ def dist_setup(args):
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.share_gpu:   # rehearsal of the multi-rank path on one card: every rank on cuda:0, gloo collectives
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     return rank, world, torch.device("cuda", local if world > 1 else 0)
