@@ -178,3 +178,27 @@ def test_sim3_ops_match_oracle(device):
     assert torch.equal(I.act(_t(X, device)), _t(X, device))
     M = T[7:8].matrix()[0].cpu().numpy()
     np.testing.assert_allclose(M[:3, :3] @ X[0] + M[:3, 3], oracle.sim3_act(Tn[7], X[:1])[0], atol=4e-6)
+
+
+def test_edge_blocks_full_resolution(device):
+    """BASELINE size: 384x512 pointmaps (196 608 points per keyframe), 4 keyframes, 10 directed edges: per-edge
+    blocks against the oracle (rel-L2 <= 1e-5) and the multi-GPU edge split (bitwise)."""
+    import mast3r_slam_backends as be
+
+    g, d = _graph(device, n_kf=4, h=384, w=512, seed=5, stride=4, extra_edges=1)
+    uniq, ie, je, io, jo = oracle.edge_rows(g["ii"], g["jj"])
+    Hs_ref, gs_ref = oracle.gn_edges("rays", g["Twc"], g["Xs"], g["Cs"], None, ie, je, g["idx_ii2jj"], g["valid_match"],
+                                     g["Q"], 0.003, 10.0, 0.0, 1.5)
+    args = ("rays", d["Twc"], d["Xs"], d["Cs"], None, d["ii"], d["jj"])
+    Hs, gs = be.gn_blocks(*args, d["idx_ii2jj"], d["valid_match"], d["Q"], 0.003, 10.0, 0.0, 1.5)
+    for e in range(Hs.shape[1]):
+        for blk in range(4):
+            assert _rel(Hs[blk, e].cpu().numpy(), Hs_ref[blk, e]) <= 1e-5
+        for blk in range(2):
+            assert _rel(gs[blk, e].cpu().numpy(), gs_ref[blk, e]) <= 1e-5
+    E = g["ii"].shape[0]
+    cut = E // 2
+    parts = [be.gn_blocks(*args, d["idx_ii2jj"][a:a + n].contiguous(), d["valid_match"][a:a + n].contiguous(),
+                          d["Q"][a:a + n].contiguous(), 0.003, 10.0, 0.0, 1.5, edge_begin=a, edge_count=n)
+             for a, n in ((0, cut), (cut, E - cut))]
+    assert torch.equal(parts[0][0] + parts[1][0], Hs) and torch.equal(parts[0][1] + parts[1][1], gs)

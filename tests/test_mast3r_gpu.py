@@ -192,3 +192,29 @@ def test_concurrent_calls_from_two_threads(device):
         assert torch.equal(w_, g_)
     for w_, g_ in zip(want_b, got["b"]):
         assert torch.equal(w_, g_)
+
+
+def test_full_size_model_matches_oracle(device):
+    """The configuration the bench runs: ViT-L encoder (24 x 1024, 16 heads), 12-layer 768-wide decoder, DPT +
+    descriptor heads, one 384x512 pair, seeded random weights; against the torch-fp32 oracle on the host.
+    Tolerances as stated at the top of this file (bf16 MFMA operands through 36 transformer layers)."""
+    cfg = R.Mast3rConfig()
+    sd, model = _model(cfg, 1, device)
+    g = torch.Generator().manual_seed(4)
+    H, W = 384, 512
+    img1 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    img2 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    with torch.inference_mode():
+        f1, p1 = R.encode_image(sd, cfg, img1)
+        f2, p2 = R.encode_image(sd, cfg, img2)
+        d1, d2 = R.decoder(sd, cfg, f1, p1, f2, p2)
+        ref1 = R.downstream_head(sd, cfg, 1, d1, H, W)
+        ref2 = R.downstream_head(sd, cfg, 2, d2, H, W)
+    hf1 = model._encode_image(img1.to(device))[0]
+    e_enc = _rel(hf1.cpu().numpy(), f1.numpy())
+    r1, r2, t1, t2 = model.decode_pair(f1.to(device), f2.to(device), H, W, return_tokens=True)
+    e_dec = max(_rel(t1.cpu().numpy(), d1[-1].numpy()), _rel(t2.cpu().numpy(), d2[-1].numpy()))
+    print(f"full-size rel-L2: encoder tokens {e_enc:.4f}, decoder tokens {e_dec:.4f}")
+    assert e_enc <= 2e-2 and e_dec <= 2e-2
+    _check_heads(r1, {k: v.numpy() for k, v in ref1.items()})
+    _check_heads(r2, {k: v.numpy() for k, v in ref2.items()})
