@@ -79,6 +79,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
   // slice of W.
   const unsigned nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   const unsigned ngrp = g.groups > 1 ? 2u : 1u;
+  if (blockIdx.x >= nbm * nbn * ngrp) {
+    // ---- prefetch role: the blocks behind the tile grid only stream the next weights through the fabric ----
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const unsigned pb = blockIdx.x - nbm * nbn * ngrp, npb = gridDim.x - nbm * nbn * ngrp;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const char* base = reinterpret_cast<const char*>(g.pf_ptr[r]);
+      const size_t bytes = g.pf_bytes[r] & ~(size_t)15;
+      const size_t stride = (size_t)npb * (64 * NW) * 16;
+      size_t off = ((size_t)pb * (64 * NW) + threadIdx.x) * 16;
+      for (; off + 15 * stride < bytes; off += 16 * stride) {   // 16 independent 16-byte loads in flight per lane
+        u32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = *reinterpret_cast<const u32x4*>(base + off + k * stride);   // default policy: allocates in the Infinity Cache
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc ^= v[k];
+      }
+      for (; off < bytes; off += stride) acc ^= *reinterpret_cast<const u32x4*>(base + off);
+    }
+    if ((acc[0] ^ acc[1]) == 0x9e3779b9u && (acc[2] ^ acc[3]) == 0x7f4a7c15u && g.pf_sink) *g.pf_sink = acc[0];
+    return;
+  }
   const unsigned logical = xcd_remap(blockIdx.x, nbm * nbn * ngrp);   // group 0 on the first XCDs, group 1 on the rest
   const unsigned prob = logical / (nbm * nbn), tile = logical - prob * (nbm * nbn);
   if (prob) {   // second problem of a grouped launch (block-uniform)
@@ -460,7 +483,8 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr size_t ring = (size_t)S * (BM + BN) * 128, patch = (size_t)NW * 32 * 40 * sizeof(float);
   constexpr size_t shmem = ring > patch ? ring : patch;
   static_assert(shmem <= 160 * 1024, "LDS budget");
-  const unsigned blocks = (unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)) * (a.groups > 1 ? 2u : 1u);
+  const unsigned blocks = (unsigned)(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN)) * (a.groups > 1 ? 2u : 1u) +
+                          ((a.pf_bytes[0] + a.pf_bytes[1]) ? (unsigned)kGemmPrefetchBlocks : 0u);
   static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
   if (!attr_set) {
     const void* fns[2] = {(const void*)gemm_bf16_kernel<WM, WN, MI, NI, S, false>,

@@ -457,6 +457,8 @@ struct Mast3rModel {
     std::vector<hipEvent_t> events;
     size_t ev_next = 0;
   };
+  unsigned* pf_sink = nullptr;           // 4 scratch bytes behind the RoPE tables (gemm.h: pf_sink)
+  bool prefetch = true;                  // MSLAM_PREFETCH=0: no weight prefetch blocks
   bool two_streams = true;
   bool dec_grouped = true;               // both decoder sides per launch (MSLAM_DEC_GROUPED=0: one queue per side)
   mutable std::mutex fork_mu;
@@ -544,6 +546,16 @@ static void run_gemm(Ctx& c, GemmArgs& g) {
   dbg(c, g.epi == EPI_ATTN ? "gemm_attn" : (g.a_conv ? "gemm_conv" : "gemm"), g.M, g.N, g.K);
 }
 
+// weights of a later launch to stream into the Infinity Cache beside this one (gemm.h: pf_ptr)
+struct Pf { const Lin* a = nullptr; const Lin* b = nullptr; };
+static void set_pf(const Ctx& c, GemmArgs& g, const Pf& pf) {
+  if (!c.m->prefetch) return;
+  const Lin* l[2] = {pf.a, pf.b};
+  for (int k = 0; k < 2; k++)
+    if (l[k]) { g.pf_ptr[k] = l[k]->W; g.pf_bytes[k] = (size_t)l[k]->out * l[k]->in * sizeof(bf16); }
+  g.pf_sink = c.m->pf_sink;
+}
+
 static GemmArgs dense_args(const bf16* A, int M, const Lin& l) {
   GemmArgs g = {};
   g.A = A; g.W = l.W; g.M = M; g.N = l.out; g.K = l.in; g.lda = l.in; g.bias = l.b;
@@ -580,8 +592,9 @@ static void cast_bf16(Ctx& c, const float* x, bf16* y, size_t n) {
 struct AttnBufs { bf16 *q, *k, *vt, *o; };
 
 static void attn_project(Ctx& c, const bf16* A, int M, const Lin& l, int sec_base, int heads, int ntok, int kv_ntok,
-                         int tok_w, const AttnBufs& ab) {
+                         int tok_w, const AttnBufs& ab, const Pf& pf = Pf()) {
   GemmArgs g = dense_args(A, M, l);
+  set_pf(c, g, pf);
   g.epi = EPI_ATTN; g.sec_base = sec_base; g.sec_dim = heads * 64; g.heads = heads; g.ntok = ntok; g.kv_ntok = kv_ntok;
   g.tok_w = tok_w; g.q_out = ab.q; g.k_out = ab.k; g.vt_out = ab.vt; g.rope_cos = c.m->rope_cos;
   g.rope_sin = c.m->rope_sin; g.q_scale = 0.125f;  // head_dim 64 ** -0.5
@@ -595,14 +608,16 @@ static void attention(Ctx& c, const AttnBufs& ab, int B, int heads, int nq, int 
 }
 
 // x (f32 residual stream, [M,D]) += Linear(A) (+bias)
-static void linear_residual(Ctx& c, const bf16* A, int M, const Lin& l, float* x) {
+static void linear_residual(Ctx& c, const bf16* A, int M, const Lin& l, float* x, const Pf& pf = Pf()) {
   GemmArgs g = dense_args(A, M, l);
+  set_pf(c, g, pf);
   g.res1 = x; g.res1_kind = KIND_F32; g.out = x; g.out_kind = KIND_F32;
   run_gemm(c, g);
 }
 
-static void linear_bf16(Ctx& c, const bf16* A, int M, const Lin& l, bf16* out, int act) {
+static void linear_bf16(Ctx& c, const bf16* A, int M, const Lin& l, bf16* out, int act, const Pf& pf = Pf()) {
   GemmArgs g = dense_args(A, M, l);
+  set_pf(c, g, pf);
   g.out = out; g.out_kind = KIND_BF16; g.act = act;
   run_gemm(c, g);
 }
@@ -626,10 +641,11 @@ static BlockScratch block_scratch(Ctx& c, int M, int D) {
   return s;
 }
 
-static void mlp_residual(Ctx& c, float* x, int M, const Norm& n, const Lin& fc1, const Lin& fc2, BlockScratch& s) {
+static void mlp_residual(Ctx& c, float* x, int M, const Norm& n, const Lin& fc1, const Lin& fc2, BlockScratch& s,
+                         const Pf& pf1 = Pf(), const Pf& pf2 = Pf()) {
   layernorm(c, x, n, M, s.h, nullptr);
-  linear_bf16(c, s.h, M, fc1, s.u, ACT_GELU);
-  linear_residual(c, s.u, M, fc2, x);
+  linear_bf16(c, s.h, M, fc1, s.u, ACT_GELU, pf1);
+  linear_residual(c, s.u, M, fc2, x, pf2);
 }
 
 // feat_out f32 [B*N, E] (enc_norm output)
@@ -648,11 +664,12 @@ static void encode(Ctx& c, const float* img, int B, int H, int W, float* feat_ou
   linear_f32(c, patches, M, m.pe, x);
   for (int i = 0; i < m.enc_depth; i++) {
     const EncBlock& b = m.enc[i];
+    const EncBlock* nb = i + 1 < m.enc_depth ? &m.enc[i + 1] : nullptr;   // each GEMM streams its successor's weights
     layernorm(c, x, b.n1, M, s.h, nullptr);
-    attn_project(c, s.h, M, b.qkv, 0, m.enc_heads, N, N, nw, s.ab);
+    attn_project(c, s.h, M, b.qkv, 0, m.enc_heads, N, N, nw, s.ab, Pf{nb ? &nb->qkv : nullptr});
     attention(c, s.ab, B, m.enc_heads, N, N);
-    linear_residual(c, s.ab.o, M, b.proj, x);
-    mlp_residual(c, x, M, b.n2, b.fc1, b.fc2, s);
+    linear_residual(c, s.ab.o, M, b.proj, x, Pf{nb ? &nb->proj : nullptr});
+    mlp_residual(c, x, M, b.n2, b.fc1, b.fc2, s, Pf{nb ? &nb->fc1 : nullptr}, Pf{nb ? &nb->fc2 : nullptr});
   }
   layernorm(c, x, m.enc_norm, M, nullptr, feat_out);
 }
@@ -775,20 +792,20 @@ static void run_head(Ctx& c, const Head& hd, const bf16* const toks[4], int B, i
   }
 }
 
-static void dec_block(Ctx& c, const DecBlock& b, float* x, const bf16* yn, int B, int N, int Nk, int nw, int nw_k,
-                      BlockScratch& s) {
+static void dec_block(Ctx& c, const DecBlock& b, const DecBlock* nb, float* x, const bf16* yn, int B, int N, int Nk, int nw,
+                      int nw_k, BlockScratch& s) {
   const Mast3rModel& m = *c.m;
   const int M = B * N, Mk = B * Nk;
   // s.h already holds norm1(x): computed together with the other side's norm_y (layernorm2 in decode())
-  attn_project(c, s.h, M, b.qkv, 0, m.dec_heads, N, N, nw, s.ab);
+  attn_project(c, s.h, M, b.qkv, 0, m.dec_heads, N, N, nw, s.ab, Pf{nb ? &nb->qkv : nullptr});
   attention(c, s.ab, B, m.dec_heads, N, N);
-  linear_residual(c, s.ab.o, M, b.proj, x);
+  linear_residual(c, s.ab.o, M, b.proj, x, Pf{nb ? &nb->proj : nullptr});
   layernorm(c, x, b.n2, M, s.h, nullptr);
-  attn_project(c, s.h, M, b.pq, 0, m.dec_heads, N, Nk, nw, s.ab);
-  attn_project(c, yn, Mk, b.pkv, 1, m.dec_heads, N, Nk, nw_k, s.ab);   // [projk; projv] stacked: sections 1 and 2
+  attn_project(c, s.h, M, b.pq, 0, m.dec_heads, N, Nk, nw, s.ab, Pf{nb ? &nb->pq : nullptr});
+  attn_project(c, yn, Mk, b.pkv, 1, m.dec_heads, N, Nk, nw_k, s.ab, Pf{nb ? &nb->pkv : nullptr});   // [projk; projv] stacked
   attention(c, s.ab, B, m.dec_heads, N, Nk);
-  linear_residual(c, s.ab.o, M, b.cproj, x);
-  mlp_residual(c, x, M, b.n3, b.fc1, b.fc2, s);
+  linear_residual(c, s.ab.o, M, b.cproj, x, Pf{nb ? &nb->cproj : nullptr});
+  mlp_residual(c, x, M, b.n3, b.fc1, b.fc2, s, Pf{nb ? &nb->fc1 : nullptr}, Pf{nb ? &nb->fc2 : nullptr});
 }
 
 // feat1/feat2 f32 [B*N, E]; outputs for both sides; dec_last (optional) f32 [2][B*N, Dd]
@@ -838,8 +855,9 @@ static void g_layernorm_cross(Ctx& c, const float* x, const DecBlock& b0, const 
 }
 
 static void g_attn_project(Ctx& c, const bf16* A, int M, const Lin& l0, const Lin& l1, int sec_base, int heads, int B,
-                           int ntok, int kv_ntok, int tok_w, const AttnBufs& ab) {
+                           int ntok, int kv_ntok, int tok_w, const AttnBufs& ab, const Pf& pf = Pf()) {
   GemmArgs g = dense_args(A, M, l0);
+  set_pf(c, g, pf);
   g.epi = EPI_ATTN; g.sec_base = sec_base; g.sec_dim = heads * 64; g.heads = heads; g.ntok = ntok; g.kv_ntok = kv_ntok;
   g.tok_w = tok_w; g.q_out = ab.q; g.k_out = ab.k; g.vt_out = ab.vt; g.rope_cos = c.m->rope_cos;
   g.rope_sin = c.m->rope_sin; g.q_scale = 0.125f;
@@ -848,38 +866,43 @@ static void g_attn_project(Ctx& c, const bf16* A, int M, const Lin& l0, const Li
   run_gemm(c, g);
 }
 
-static void g_linear_residual(Ctx& c, const bf16* A, int M, const Lin& l0, const Lin& l1, float* x) {
+static void g_linear_residual(Ctx& c, const bf16* A, int M, const Lin& l0, const Lin& l1, float* x, const Pf& pf = Pf()) {
   GemmArgs g = dense_args(A, M, l0);
+  set_pf(c, g, pf);
   g.res1 = x; g.res1_kind = KIND_F32; g.out = x; g.out_kind = KIND_F32;
   group2(g, l1, (size_t)M * l0.in, (size_t)M * l0.out * sizeof(float));
   g.res1_gbytes = g.out_gbytes;
   run_gemm(c, g);
 }
 
-static void g_linear_bf16(Ctx& c, const bf16* A, int M, const Lin& l0, const Lin& l1, bf16* out, int act) {
+static void g_linear_bf16(Ctx& c, const bf16* A, int M, const Lin& l0, const Lin& l1, bf16* out, int act,
+                          const Pf& pf = Pf()) {
   GemmArgs g = dense_args(A, M, l0);
+  set_pf(c, g, pf);
   g.out = out; g.out_kind = KIND_BF16; g.act = act;
   group2(g, l1, (size_t)M * l0.in, (size_t)M * l0.out * sizeof(bf16));
   run_gemm(c, g);
 }
 
 // one decoder layer for both sides; x [2M, Dd] f32; scratch s sized for 2M rows
-static void dec_layer_grouped(Ctx& c, const DecBlock& b0, const DecBlock& b1, float* x, bf16* yn, int B, int N, int nw,
-                              BlockScratch& s) {
+static void dec_layer_grouped(Ctx& c, const DecBlock& b0, const DecBlock& b1, const DecBlock* n0, const DecBlock* n1,
+                              float* x, bf16* yn, int B, int N, int nw, BlockScratch& s) {
   const Mast3rModel& m = *c.m;
   const int M = B * N;
+#define MSLAM_PF(field) (n0 ? Pf{&n0->field, &n1->field} : Pf{})   /* the next layer's matrices of both sides */
   g_layernorm_cross(c, x, b0, b1, M, s.h, yn);
-  g_attn_project(c, s.h, M, b0.qkv, b1.qkv, 0, m.dec_heads, B, N, N, nw, s.ab);
+  g_attn_project(c, s.h, M, b0.qkv, b1.qkv, 0, m.dec_heads, B, N, N, nw, s.ab, MSLAM_PF(qkv));
   attention(c, s.ab, 2 * B, m.dec_heads, N, N);
-  g_linear_residual(c, s.ab.o, M, b0.proj, b1.proj, x);
+  g_linear_residual(c, s.ab.o, M, b0.proj, b1.proj, x, MSLAM_PF(proj));
   g_layernorm(c, x, b0.n2, b1.n2, M, s.h);
-  g_attn_project(c, s.h, M, b0.pq, b1.pq, 0, m.dec_heads, B, N, N, nw, s.ab);
-  g_attn_project(c, yn, M, b0.pkv, b1.pkv, 1, m.dec_heads, B, N, N, nw, s.ab);
+  g_attn_project(c, s.h, M, b0.pq, b1.pq, 0, m.dec_heads, B, N, N, nw, s.ab, MSLAM_PF(pq));
+  g_attn_project(c, yn, M, b0.pkv, b1.pkv, 1, m.dec_heads, B, N, N, nw, s.ab, MSLAM_PF(pkv));
   attention(c, s.ab, 2 * B, m.dec_heads, N, N);
-  g_linear_residual(c, s.ab.o, M, b0.cproj, b1.cproj, x);
+  g_linear_residual(c, s.ab.o, M, b0.cproj, b1.cproj, x, MSLAM_PF(cproj));
   g_layernorm(c, x, b0.n3, b1.n3, M, s.h);
-  g_linear_bf16(c, s.h, M, b0.fc1, b1.fc1, s.u, ACT_GELU);
-  g_linear_residual(c, s.u, M, b0.fc2, b1.fc2, x);
+  g_linear_bf16(c, s.h, M, b0.fc1, b1.fc1, s.u, ACT_GELU, MSLAM_PF(fc1));
+  g_linear_residual(c, s.u, M, b0.fc2, b1.fc2, x, MSLAM_PF(fc2));
+#undef MSLAM_PF
 }
 
 // feat1/feat2 f32 [B*N, E]; outputs for both sides; dec_last (optional) f32 [2][B*N, Dd].
@@ -931,7 +954,9 @@ static void decode(Ctx& c, const float* feat1, const float* feat2, int B, int H,
     cast_bf16(c, feat[1], fb[1], ME);
     linear_f32(c, fb_all, 2 * M, m.dec_embed, x_all);          // decoder_embed is shared by the two sides
     for (int l = 0; l < m.dec_depth; l++) {
-      dec_layer_grouped(c, m.dec[0][l], m.dec[1][l], x_all, yn_all, B, N, nw, bs_all);
+      const bool more = l + 1 < m.dec_depth;
+      dec_layer_grouped(c, m.dec[0][l], m.dec[1][l], more ? &m.dec[0][l + 1] : nullptr, more ? &m.dec[1][l + 1] : nullptr,
+                        x_all, yn_all, B, N, nw, bs_all);
       for (int k = 1; k < 3; k++)
         if (l + 1 == m.hooks[k]) cast_bf16(c, x_all, tok_all[k], 2 * MD);
     }
@@ -951,7 +976,7 @@ static void decode(Ctx& c, const float* feat1, const float* feat2, int B, int H,
     if (sB != sA) stream_wait(c, sB, sA);                     // memories ready; x[0] final for side 2's reads
     for (int s = 0; s < 2; s++) {
       c.s = st[s]; c.side = s;
-      dec_block(c, m.dec[s][l], x[s], yn[s], B, N, N, nw, nw, bs[s]);
+      dec_block(c, m.dec[s][l], l + 1 < m.dec_depth ? &m.dec[s][l + 1] : nullptr, x[s], yn[s], B, N, N, nw, nw, bs[s]);
       for (int k = 1; k < 3; k++)
         if (l + 1 == m.hooks[k]) cast_bf16(c, x[s], tok[s][k], (size_t)M * m.Dd);
     }
@@ -1050,12 +1075,14 @@ extern "C" int mslam_mast3r_create(void** handle_out, const int* cfg9, void* con
       hc[(size_t)p * 16 + i] = cosf(fr);
       hs[(size_t)p * 16 + i] = sinf(fr);
     }
-  int rc = check_hip(hipMalloc(&m->rope_cos, hc.size() * 4), "rope hipMalloc");
+  int rc = check_hip(hipMalloc(&m->rope_cos, hc.size() * 4 + 16), "rope hipMalloc");
+  if (!rc) m->pf_sink = reinterpret_cast<unsigned*>(m->rope_cos + hc.size());
   if (!rc) rc = check_hip(hipMalloc(&m->rope_sin, hs.size() * 4), "rope hipMalloc");
   if (!rc) rc = check_hip(hipMemcpyAsync(m->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream), "rope copy");
   if (!rc) rc = check_hip(hipMemcpyAsync(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream), "rope copy");
   if (!rc) rc = check_hip(hipStreamSynchronize((hipStream_t)stream), "rope sync");
   m->two_streams = getenv("MSLAM_SINGLE_STREAM") == nullptr;
+  if (const char* e = getenv("MSLAM_PREFETCH")) m->prefetch = atoi(e) != 0;
   if (const char* e = getenv("MSLAM_DEC_GROUPED")) m->dec_grouped = atoi(e) != 0;
   if (rc) { delete m; return rc; }
   *handle_out = m;
