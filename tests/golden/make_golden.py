@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -343,6 +343,47 @@ def section_resize():
     print("resize:", {k: v.shape for k, v in out.items() if k.endswith("_uimg")})
 
 
+def section_geometry():
+    """geometry.py / nonlinear_optimizer.py: every tensor helper, float64, seeded inputs (lietorch stubbed as in
+    the tracker section: geometry.py only needs the name for an annotation and a pose with .act())."""
+    import types
+
+    from mast3r_slam import synthetic
+
+    sys.modules.setdefault("lietorch", types.SimpleNamespace(Sim3=object))
+    geom = load_by_path("ref_geometry2", f"{REF}/mast3r_slam/geometry.py")
+    nlo = load_by_path("ref_nlo2", f"{REF}/mast3r_slam/nonlinear_optimizer.py")
+    g = torch.Generator().manual_seed(12)
+    X = torch.randn(5, 7, 3, generator=g, dtype=torch.float64) + torch.tensor([0.0, 0.0, 2.5], dtype=torch.float64)
+    X[0, 0, 2] = -0.3   # behind the camera
+    K = torch.tensor([[400.0, 0, 31.5], [0, 380.0, 23.5], [0, 0, 1]], dtype=torch.float64)
+    T = np.array([0.1, -0.2, 0.05, 0.1, -0.05, 0.2, 0.97, 1.3], np.float64)
+    T[3:7] /= np.linalg.norm(T[3:7])
+
+    class Pose:
+        def act(self, P):
+            return torch.from_numpy(synthetic.sim3_act(T, P.numpy()))
+
+    out = dict(X=X.numpy(), K=K.numpy(), T=T)
+    out["skew"] = geom.skew_sym(X).numpy()
+    out["dist"] = geom.point_to_dist(X).numpy()
+    rd, J = geom.point_to_ray_dist(X, jacobian=True)
+    out["rd"], out["rd_J"] = rd.numpy(), J.numpy()
+    pz, Jp, valid = geom.project_calib(X, K, (48, 64), jacobian=True, border=2, z_eps=1e-6)
+    out["pz"], out["pz_J"], out["pz_valid"] = pz.numpy(), Jp.numpy(), valid.numpy()
+    pW, Ja = geom.act_Sim3(Pose(), X, jacobian=True)
+    out["act"], out["act_J"] = pW.numpy(), Ja.numpy()
+    out["bp"] = geom.backproject(pz[..., :2], X[..., 2:3], K).numpy()
+    out["ray"] = geom.constrain_points_to_ray((5, 7), X[None], K).numpy()
+    r = torch.linspace(-6, 6, 41, dtype=torch.float64)
+    out["r"], out["huber"], out["tukey"] = r.numpy(), nlo.huber(r).numpy(), nlo.tukey(r).numpy()
+    out["conv"] = np.array([nlo.check_convergence(0, 1e-3, 1e-3, 10.0, c, torch.tensor([d, 0.0]))
+                            for c, d in ((9.0, 1.0), (9.9999, 1.0), (5.0, 1e-4))])
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **out, **meta())
+    print("geometry.npz", sorted(out))
+
+
+SECTIONS["geometry"] = section_geometry
 SECTIONS["resize"] = section_resize
 
 
