@@ -460,6 +460,7 @@ struct Mast3rModel {
   unsigned* pf_sink = nullptr;           // 4 scratch bytes behind the RoPE tables (gemm.h: pf_sink)
   bool prefetch = true;                  // MSLAM_PREFETCH=0: no weight prefetch blocks
   bool two_streams = true;
+  int fork_max_rows = 1 << 30;           // MSLAM_FORK_MAX_M: calls with more token rows per side stay on one queue
   bool dec_grouped = true;               // both decoder sides per launch (MSLAM_DEC_GROUPED=0: one queue per side)
   mutable std::mutex fork_mu;
   mutable std::map<hipStream_t, Fork*> forks;
@@ -915,7 +916,7 @@ static void decode(Ctx& c, const float* feat1, const float* feat2, int B, int H,
   const int nh = H / m.P, nw = W / m.P, N = nh * nw, M = B * N;
   const float* feat[2] = {feat1, feat2};
   float* dec_last[2] = {dec_last1, dec_last2};
-  if (!c.dry() && m.two_streams && !c.rc) {
+  if (!c.dry() && m.two_streams && !c.rc && M <= m.fork_max_rows) {
     int frc = MSLAM_OK;
     c.fk = m.fork_for(c.s, frc);
     c.fail(frc);
@@ -1082,6 +1083,7 @@ extern "C" int mslam_mast3r_create(void** handle_out, const int* cfg9, void* con
   if (!rc) rc = check_hip(hipMemcpyAsync(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream), "rope copy");
   if (!rc) rc = check_hip(hipStreamSynchronize((hipStream_t)stream), "rope sync");
   m->two_streams = getenv("MSLAM_SINGLE_STREAM") == nullptr;
+  if (const char* e = getenv("MSLAM_FORK_MAX_M")) m->fork_max_rows = atoi(e);
   if (const char* e = getenv("MSLAM_PREFETCH")) m->prefetch = atoi(e) != 0;
   if (const char* e = getenv("MSLAM_DEC_GROUPED")) m->dec_grouped = atoi(e) != 0;
   if (rc) { delete m; return rc; }
