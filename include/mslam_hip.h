@@ -281,6 +281,20 @@ int mslam_tsdf_local_raycast(const float* tsdf, int nx, int ny, int nz, const fl
                              const float* xyz_max, const float* X_original, const int64_t* sel_pix, int n_sel,
                              int n_samples, float max_displacement, float* surf, uint8_t* hit, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Quality service patch statistics: replaces the torch reshape + nanmedian pipeline of
+ * mast3r_slam/quality_core.py.  reduce_grid (:15-29) / u_from_CQ (:45-52) / r_from_scalar (:54-55) /
+ * valid_grid (:57-59): one value per ps x ps patch of an h x w map, out f32[(h/ps)*(w/ps)].
+ *   mode 0: nanmedian of x over valid pixels (valid u8[h*w] or NULL), empty patch -> 0
+ *   mode 1: mean (valid NULL) / nanmean over valid pixels
+ *   mode 2: median of U = 1 - sqrt(clamp(C/(c_thr+1e-8)) * clamp(Q/(q_thr+1e-8))), x = C, y = Q
+ * classify (:66-117): robust z-scores of r and u over the n-patch grid, class ids int64[n], normalised priority f32[n].
+ * ------------------------------------------------------------------------------------------ */
+int mslam_quality_reduce_grid(const float* x, const float* y, const uint8_t* valid, int h, int w, int ps, int mode,
+                              double c_thr, double q_thr, float* out, void* stream);
+int mslam_quality_classify(const float* delta_cov, const float* r, const float* u, int n, float thr_zr, float thr_zu,
+                           float thr_dc, int64_t* cls, float* pri, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

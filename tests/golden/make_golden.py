@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -383,6 +383,36 @@ def section_geometry():
     print("geometry.npz", sorted(out))
 
 
+def section_quality():
+    """quality_core.py (pure torch, importable as is): compute_batch on two seeded jobs plus the individual reducers."""
+    qc = load_by_path("ref_quality_core", f"{REF}/mast3r_slam/quality_core.py")
+    out = {}
+    for name, (h, w, ps) in {"a": (96, 128, 16), "b": (64, 64, 8)}.items():
+        g = torch.Generator().manual_seed(len(name) + h)
+        valid = torch.rand(h * w, generator=g) > 0.35
+        valid.view(h, w)[:ps, :ps] = False                      # one empty patch: nanmedian -> NaN -> 0
+        r_pix = torch.rand(h * w, generator=g) * 0.05
+        r_pix[::97] = float("nan")                              # NaNs inside valid pixels are ignored too
+        Ck = torch.rand(h * w, 1, generator=g) * 4.0
+        Qk = torch.rand(h * w, 1, generator=g) * 3.0
+        job = dict(kf_id=3, H=h, W=w, valid_kf=valid, r_pix=r_pix, Ck=Ck, Qk=Qk, t_norm=torch.tensor(0.04),
+                   theta=torch.tensor(0.12))
+        if name == "b":
+            job["cov_ewma"] = torch.rand(h // ps, w // ps, generator=g)
+        res = qc.compute_batch([dict(job)], ps, 0.8, 0.1, 0.26, 2.0, 1.5, 1.0, 1.0, 0.02, "cpu")[0]
+        for k in ("valid_kf", "r_pix", "Ck", "Qk"):
+            out[f"{name}_{k}"] = job[k].numpy()
+        if "cov_ewma" in job:
+            out[f"{name}_prev"] = job["cov_ewma"].numpy()
+        for k in ("delta_cov", "r", "u", "class_id", "priority", "cov_ewma"):
+            out[f"{name}_out_{k}"] = np.asarray(res[k])
+        out[f"{name}_mean"] = qc.reduce_grid(r_pix.nan_to_num(0.0), h, w, ps, valid=valid, method="mean").numpy()
+        out[f"{name}_hwps"] = np.array([h, w, ps])
+    np.savez_compressed(os.path.join(HERE, "quality_core.npz"), **out, **meta())
+    print("quality_core.npz", {k: v.shape for k, v in out.items() if "_out_" in k})
+
+
+SECTIONS["quality"] = section_quality
 SECTIONS["geometry"] = section_geometry
 SECTIONS["resize"] = section_resize
 
