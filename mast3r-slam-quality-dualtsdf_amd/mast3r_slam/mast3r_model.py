@@ -124,6 +124,7 @@ class Mast3rHIP:
         self.device = torch.device(device)
         self.use_graphs = bool(use_graphs)
         self._graphs = {}
+        self._pos_cache = {}
         self._weights = canonical_weights(state_dict, self.cfg, self.device)
         n = len(self._weights)
         ptrs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in self._weights])
@@ -167,9 +168,12 @@ class Mast3rHIP:
 
     def positions(self, B, H, W):
         """PositionGetter (croco/models/blocks.py:195-207): (B, N, 2) int64 [y, x]."""
-        nh, nw = H // self.cfg.patch, W // self.cfg.patch
-        y, x = torch.meshgrid(torch.arange(nh, device=self.device), torch.arange(nw, device=self.device), indexing="ij")
-        return torch.stack((y.reshape(-1), x.reshape(-1)), -1)[None].expand(B, -1, 2).clone()
+        key = (B, H, W)
+        if key not in self._pos_cache:   # constant per shape: built once, handed out as a fresh copy
+            nh, nw = H // self.cfg.patch, W // self.cfg.patch
+            y, x = torch.meshgrid(torch.arange(nh, device=self.device), torch.arange(nw, device=self.device), indexing="ij")
+            self._pos_cache[key] = torch.stack((y.reshape(-1), x.reshape(-1)), -1)[None].expand(B, -1, 2).contiguous()
+        return self._pos_cache[key].clone()
 
     @torch.inference_mode()
     def _encode_image(self, image, true_shape=None):

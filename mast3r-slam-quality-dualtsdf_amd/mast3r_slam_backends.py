@@ -20,8 +20,10 @@ def iter_proj(rays_img_with_grad, pts_3d_norm, p_init, max_iter, lambda_init, co
     if c != 9:
         raise RuntimeError(f"rays_img_with_grad must have 9 channels, got {c}")
     n = p_init.shape[1]
-    p_new = torch.zeros((b, n, 2), dtype=p_init.dtype, device=p_init.device)
-    converged = torch.zeros((b, n), dtype=torch.bool, device=p_init.device)
+    # the reference allocates with torch::zeros (matching_kernels.cu:295-301); the kernel writes every element, so
+    # the fill launches are skipped here
+    p_new = torch.empty((b, n, 2), dtype=p_init.dtype, device=p_init.device)
+    converged = torch.empty((b, n), dtype=torch.bool, device=p_init.device)
     rc = _m.lib().mslam_iter_proj(
         _m.ptr(rays_img_with_grad), _m.ptr(pts_3d_norm), _m.ptr(p_init), _m.ptr(p_new), _m.ptr(converged),
         b, h, w, n, int(max_iter), float(lambda_init), float(cost_thresh), _m.stream_ptr(),
@@ -41,7 +43,7 @@ def refine_matches(D11, D21, p1, radius, dilation_max):
     _m.require_dtype(p1, torch.int64, "p1")
     b, h, w, f = D11.shape
     n = p1.shape[1]
-    p1_new = torch.zeros((b, n, 2), dtype=p1.dtype, device=p1.device)
+    p1_new = torch.empty((b, n, 2), dtype=p1.dtype, device=p1.device)   # fully written by the kernel
     rc = _m.lib().mslam_refine_matches(
         _m.ptr(D11), _m.ptr(D21), _m.ptr(p1), _m.ptr(p1_new), b, h, w, n, f, int(radius), int(dilation_max),
         _m.stream_ptr(),
