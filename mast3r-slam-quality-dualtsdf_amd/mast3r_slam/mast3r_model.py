@@ -286,7 +286,12 @@ def load_mast3r_state_dict(path):
     if not os.path.isfile(path):
         raise FileNotFoundError(
             f"{path}: MASt3R checkpoint not found (the reference downloads it, README.md:63-65; no network here)")
-    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    # weights_only=True; the only non-tensor object of an upstream checkpoint is ckpt["args"], an argparse.Namespace
+    # (a plain attribute container), which is allow-listed explicitly - nothing from the file is executed
+    import argparse
+
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
     return ckpt["model"] if "model" in ckpt else ckpt
 
 

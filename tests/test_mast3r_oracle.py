@@ -40,3 +40,22 @@ def test_forward_matches_reference_model(fx):
                 rel = np.linalg.norm(a - b) / np.linalg.norm(b)
                 assert rel < 1e-5, (h, k, rel)
                 np.testing.assert_allclose(a, b, atol=1e-3, rtol=1e-3, err_msg=f"head{h} {k}")
+
+
+def test_checkpoint_loader_accepts_upstream_layout(tmp_path):
+    """load_mast3r_state_dict reads {'args': Namespace, 'model': state_dict} (mast3r/model.py:24-34) with the
+    weights-only loader; a missing file raises FileNotFoundError naming the reference's download step."""
+    import argparse
+
+    import pytest
+
+    from mast3r_slam.mast3r_model import load_mast3r_state_dict
+
+    p = tmp_path / "ck.pth"
+    torch.save({"args": argparse.Namespace(model="AsymmetricMASt3R(...)"), "model": {"enc_norm.weight": torch.ones(4)}, "epoch": 3}, p)
+    sd = load_mast3r_state_dict(str(p))
+    assert list(sd) == ["enc_norm.weight"] and torch.equal(sd["enc_norm.weight"], torch.ones(4))
+    torch.save({"enc_norm.weight": torch.zeros(2)}, p)     # bare state dict
+    assert list(load_mast3r_state_dict(str(p))) == ["enc_norm.weight"]
+    with pytest.raises(FileNotFoundError):
+        load_mast3r_state_dict(str(tmp_path / "missing.pth"))
