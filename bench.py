@@ -167,6 +167,8 @@ class Pipeline:
         E = args.edges_per_kf
         self.feat_i = self.kf_feat.expand(E, -1, -1).contiguous()
         self.feat_j = self.model._encode_image(self.frames[1], ts)[0].expand(E, -1, -1).contiguous()
+        self.feat_ij = torch.cat((self.feat_i, self.feat_j))
+        self.feat_ji = torch.cat((self.feat_j, self.feat_i))
         g = synthetic.make_graph(n_kf=args.graph_kfs * world, h=H, w=W, seed=11, stride=4, extra_edges=2, pose_noise=0.01)
         self.graph = {k: t(v) for k, v in g.items() if isinstance(v, np.ndarray)}
         self.vol = TSDFVolume(0.03, 0.12, capacity=1 << 22, device=dev, shard_id=rank, num_shards=world)
@@ -262,8 +264,8 @@ class Pipeline:
         import mast3r_slam_backends as be
 
         a, c = self.args, self.cfg
-        self._net(lambda: self.model.decode_pair(self.feat_i, self.feat_j, H, W))
-        self._net(lambda: self.model.decode_pair(self.feat_j, self.feat_i, H, W))
+        # symmetric inference of the E edges: both directions in one call of batch 2E (mast3r_decode_symmetric_batch)
+        self._net(lambda: self.model.decode_pair(self.feat_ij, self.feat_ji, H, W))
         E = a.edges_per_kf
         X11 = torch.cat([p["X11"] for p in self.pairs] * E)[: 2 * E]
         X21 = torch.cat([p["X21"] for p in self.pairs] * E)[: 2 * E]
@@ -317,8 +319,7 @@ class Pipeline:
             for k in range(frames if rep else 1):
                 feat = timed(lambda: self.model._encode_image(self.frames[k % len(self.frames)], ts)[0])
                 timed(lambda: self.model.decode_pair(feat, self.kf_feat, H, W))
-            timed(lambda: self.model.decode_pair(self.feat_i, self.feat_j, H, W))
-            timed(lambda: self.model.decode_pair(self.feat_j, self.feat_i, H, W))
+            timed(lambda: self.model.decode_pair(self.feat_ij, self.feat_ji, H, W))
             torch.cuda.synchronize()
         ms = sum(e0.elapsed_time(e1) for e0, e1 in evs)
         return frames * self.flop_scale * GF_TRACK + a.edges_per_kf * GF_EDGE, ms

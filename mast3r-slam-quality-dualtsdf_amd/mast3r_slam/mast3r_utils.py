@@ -64,16 +64,14 @@ def mast3r_symmetric_inference(model, frame_i, frame_j):
 @torch.inference_mode()
 def mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
     """mast3r_utils.py:83-115.  The reference loops over the B edges in Python (one decoder call per
-    edge and direction); here each direction is ONE batched native call over all B edges."""
+    edge and direction); here all edges and both directions are ONE batched native call."""
     H, W = _hw(shape_i[0])
-    r11, r21 = model.decode_pair(feat_i, feat_j, H, W)
-    r22, r12 = model.decode_pair(feat_j, feat_i, H, W)
-    order = (r11, r21, r22, r12)
-    X = torch.stack([r["pts3d"] for r in order])      # (4, B, H, W, 3)
-    C = torch.stack([r["conf"] for r in order])
-    D = torch.stack([r["desc"] for r in order])
-    Q = torch.stack([r["desc_conf"] for r in order])
-    return downsample(X, C, D, Q)
+    B = feat_i.shape[0]
+    # both directions of all B edges in ONE native call of batch 2B: rows [0, B) decode (i, j), rows [B, 2B) decode
+    # (j, i); results are bitwise those of separate calls (no arithmetic depends on the batch size)
+    ra, rb = model.decode_pair(torch.cat((feat_i, feat_j)), torch.cat((feat_j, feat_i)), H, W)
+    pick = lambda k: torch.stack((ra[k][:B], rb[k][:B], ra[k][B:], rb[k][B:]))      # order [ii, ji, jj, ij]
+    return downsample(pick("pts3d"), pick("conf"), pick("desc"), pick("desc_conf"))  # X: (4, B, H, W, 3)
 
 
 @torch.inference_mode()
