@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void refine_matches_kernel(
         const long long v = v0 - rd + jj;
         const int vi = (int)v;
         if (vi < 0 || vi >= h) continue;
-        const h16* d11 = img + ((size_t)v * w + (size_t)u) * fdim;
+        // in range here, so 32-bit element arithmetic (the image is < 2^31 halves); 64-bit products cost 4x the VALU
+        const h16* d11 = img + ((unsigned)vi * (unsigned)w + (unsigned)ui) * (unsigned)fdim;
         h16 score;
         if constexpr (FDIM > 0) {
           score = half_dot_seq<FDIM>(a, d11);
