@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -412,6 +412,66 @@ def section_quality():
     print("quality_core.npz", {k: v.shape for k, v in out.items() if "_out_" in k})
 
 
+def section_frame():
+    """Frame.update_pointmap / get_average_conf (frame.py:17-108) in every filtering mode, and the reference's default
+    configuration (config/base.yaml through its own loader).  frame.py imports lietorch and mast3r_utils (neither
+    importable here): both are stubbed for the duration of the section - the Frame arithmetic does not touch them."""
+    import json
+    import types
+
+    saved = {k: sys.modules.get(k) for k in ("lietorch", "mast3r_slam", "mast3r_slam.config", "mast3r_slam.mast3r_utils")}
+    try:
+        class _Sim3:
+            embedded_dim = 8
+
+            @staticmethod
+            def Identity(*a, **k):
+                return None
+
+        sys.modules["lietorch"] = types.SimpleNamespace(Sim3=_Sim3)
+        ref_config = load_by_path("ref_config", f"{REF}/mast3r_slam/config.py")
+        pkg = types.ModuleType("mast3r_slam")
+        pkg.__path__ = []
+        sys.modules["mast3r_slam"] = pkg
+        sys.modules["mast3r_slam.config"] = ref_config
+        sys.modules["mast3r_slam.mast3r_utils"] = types.SimpleNamespace(resize_img=None)
+        cwd = os.getcwd()
+        os.chdir(REF)
+        try:
+            ref_config.load_config("config/base.yaml")
+        finally:
+            os.chdir(cwd)
+        base = json.loads(json.dumps(ref_config.config))          # plain dict / list / numbers
+        frame = load_by_path("ref_frame", f"{REF}/mast3r_slam/frame.py")
+        g = torch.Generator().manual_seed(21)
+        n = 40
+        Xs = [torch.randn(n, 3, generator=g) + torch.tensor([0.0, 0.0, 3.0]) for _ in range(4)]
+        Cs = [torch.rand(n, 1, generator=g) * 3 for _ in range(4)]
+        out = dict(X=torch.stack(Xs).numpy(), C=torch.stack(Cs).numpy())
+        for mode in ("first", "recent", "best_score", "indep_conf", "weighted_pointmap", "weighted_spherical"):
+            ref_config.config["tracking"]["filtering_mode"] = mode
+            for score in (("median", "mean") if mode == "best_score" else ("median",)):
+                ref_config.config["tracking"]["filtering_score"] = score
+                f = frame.Frame(0, None, None, None, None)
+                for k in range(4):
+                    f.update_pointmap(Xs[k], Cs[k])
+                    tag = f"{mode}_{score}_{k}"
+                    out[tag + "_X"], out[tag + "_C"] = f.X_canon.numpy().copy(), f.C.numpy().copy()
+                    out[tag + "_N"] = np.array([f.N, f.N_updates])
+                    out[tag + "_avg"] = f.get_average_conf().numpy().copy()
+        np.savez_compressed(os.path.join(HERE, "frame_update.npz"), **out, **meta())
+        with open(os.path.join(HERE, "reference_base_config.json"), "w") as fh:
+            json.dump(base, fh, indent=1, sort_keys=True)
+        print("frame_update.npz", len(out), "arrays; reference_base_config.json", sorted(base))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+SECTIONS["frame"] = section_frame
 SECTIONS["quality"] = section_quality
 SECTIONS["geometry"] = section_geometry
 SECTIONS["resize"] = section_resize
