@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -471,6 +471,75 @@ def section_frame():
                 sys.modules[k] = v
 
 
+def section_factor_graph():
+    """FactorGraph.add_factors / prep_two_way_edges / get_unique_kf_idx (global_opt.py:12-112) on the host: the
+    reference module is loaded with its unimportable dependencies stubbed (lietorch, the compiled backends) and
+    mast3r_match_symmetric replaced by a function that returns seeded match tensors, so what is recorded is the
+    edge-acceptance and bookkeeping logic itself."""
+    import types
+
+    names = ("lietorch", "mast3r_slam", "mast3r_slam.config", "mast3r_slam.mast3r_utils", "mast3r_slam.frame",
+             "mast3r_slam.geometry", "mast3r_slam_backends")
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        sys.modules["lietorch"] = types.SimpleNamespace(Sim3=object)
+        sys.modules["mast3r_slam_backends"] = types.SimpleNamespace()
+        ref_config = load_by_path("ref_config_fg", f"{REF}/mast3r_slam/config.py")
+        ref_config.config.update({"local_opt": {"Q_conf": 1.5, "window_size": 1e6}})
+        pkg = types.ModuleType("mast3r_slam"); pkg.__path__ = []
+        sys.modules["mast3r_slam"] = pkg
+        sys.modules["mast3r_slam.config"] = ref_config
+        sys.modules["mast3r_slam.frame"] = types.SimpleNamespace(SharedKeyframes=object)
+        sys.modules["mast3r_slam.geometry"] = types.SimpleNamespace(constrain_points_to_ray=None)
+        store = {}
+        sys.modules["mast3r_slam.mast3r_utils"] = types.SimpleNamespace(
+            mast3r_match_symmetric=lambda model, fi, pi, fj, pj, si, sj: store["res"])
+        go = load_by_path("ref_global_opt", f"{REF}/mast3r_slam/global_opt.py")
+        HWn, out = 60, {}
+
+        class KF:
+            def __init__(self):
+                self.feat = torch.zeros(1, 4, 8); self.pos = torch.zeros(1, 4, 2, dtype=torch.long)
+                self.img_true_shape = torch.tensor([[6, 10]])
+
+        frames = [KF() for _ in range(8)]
+        g = torch.Generator().manual_seed(33)
+        fg = go.FactorGraph(None, frames, device="cpu")
+        calls = [([0], [1], False), ([0, 1, 1], [2, 2, 3], False), ([0, 2], [4, 4], True), ([3], [4], False)]
+        for c, (ii, jj, is_reloc) in enumerate(calls):
+            b = len(ii)
+            idx_i2j = torch.randint(0, HWn, (b, HWn), generator=g)
+            idx_j2i = torch.randint(0, HWn, (b, HWn), generator=g)
+            # per-edge valid fractions around min_match_frac = 0.3: (1,2) is consecutive and kept although poor, (1,3) is
+            # rejected, the relocalisation call contains one poor edge and must add nothing and return False
+            fr = torch.tensor([[0.95], [0.95, 0.1, 0.2], [0.95, 0.15], [0.95]][c])
+            vj = torch.rand(b, HWn, 1, generator=g) < fr[:, None, None]
+            vi = torch.rand(b, HWn, 1, generator=g) < fr[:, None, None]
+            Qs = [torch.rand(b, HWn, 1, generator=g) * 4 for _ in range(4)]
+            store["res"] = (idx_i2j, idx_j2i, vj, vi, *Qs)
+            ret = fg.add_factors(ii, jj, 0.3, is_reloc=is_reloc)
+            for k, v in zip(("idx_i2j", "idx_j2i", "vj", "vi", "Qii", "Qjj", "Qji", "Qij"), store["res"]):
+                out[f"call{c}_{k}"] = v.numpy()
+            out[f"call{c}_ii"], out[f"call{c}_jj"] = np.array(ii), np.array(jj)
+            out[f"call{c}_reloc"], out[f"call{c}_ret"] = np.array(is_reloc), np.array(bool(ret))
+            for k in ("ii", "jj", "idx_ii2jj", "idx_jj2ii", "valid_match_j", "valid_match_i", "Q_ii2jj", "Q_jj2ii"):
+                out[f"state{c}_{k}"] = getattr(fg, k).numpy().copy()
+        two = fg.prep_two_way_edges()
+        for k, v in zip(("ii", "jj", "idx", "valid", "Q"), two):
+            out[f"two_way_{k}"] = v.numpy()
+        out["unique"] = fg.get_unique_kf_idx().numpy()
+        np.savez_compressed(os.path.join(HERE, "factor_graph.npz"), **out, **meta())
+        print("factor_graph.npz: edges kept", out["state3_ii"].tolist(), out["state3_jj"].tolist(),
+              "returns", [bool(out[f"call{c}_ret"]) for c in range(4)])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+SECTIONS["factor_graph"] = section_factor_graph
 SECTIONS["frame"] = section_frame
 SECTIONS["quality"] = section_quality
 SECTIONS["geometry"] = section_geometry
