@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -539,6 +539,113 @@ def section_factor_graph():
                 sys.modules[k] = v
 
 
+def section_track_logic():
+    """FrameTracker.track (tracker.py:28-179) around the pose solver: confidence products, validity masks, the
+    match-fraction gate, keyframe pointmap fusion through the solved relative pose, the new-keyframe rule.  The
+    reference class runs here with mast3r_match_asymmetric and opt_pose_ray_dist_sim3 replaced by functions that
+    return seeded tensors / fixed poses (the solver itself is pinned elsewhere)."""
+    import types
+
+    from mast3r_slam import synthetic as syn
+
+    names = ("lietorch", "mast3r_slam", "mast3r_slam.config", "mast3r_slam.mast3r_utils", "mast3r_slam.frame",
+             "mast3r_slam.geometry", "mast3r_slam.nonlinear_optimizer")
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        class _Sim3:
+            embedded_dim = 8
+
+            @staticmethod
+            def Identity(*a, **k):
+                return None
+
+        sys.modules["lietorch"] = types.SimpleNamespace(Sim3=_Sim3)
+        ref_config = load_by_path("ref_config_tr", f"{REF}/mast3r_slam/config.py")
+        ref_config.config.update({"use_calib": False, "tracking": {
+            "C_conf": 0.0, "Q_conf": 1.5, "min_match_frac": 0.05, "match_frac_thresh": 0.333, "filtering_mode": "weighted_pointmap",
+            "filtering_score": "median"}})
+        pkg = types.ModuleType("mast3r_slam"); pkg.__path__ = []
+        sys.modules["mast3r_slam"] = pkg
+        sys.modules["mast3r_slam.config"] = ref_config
+        store = {}
+        sys.modules["mast3r_slam.mast3r_utils"] = types.SimpleNamespace(
+            resize_img=None, mast3r_match_asymmetric=lambda model, fi, fj, idx_i2j_init=None: store["match"])
+        sys.modules["mast3r_slam.frame"] = load_by_path("ref_frame_tr", f"{REF}/mast3r_slam/frame.py")
+        sys.modules["mast3r_slam.geometry"] = load_by_path("ref_geometry_tr", f"{REF}/mast3r_slam/geometry.py")
+        sys.modules["mast3r_slam.nonlinear_optimizer"] = load_by_path("ref_nlo_tr", f"{REF}/mast3r_slam/nonlinear_optimizer.py")
+        trk = load_by_path("ref_tracker", f"{REF}/mast3r_slam/tracker.py")
+        Frame = sys.modules["mast3r_slam.frame"].Frame
+
+        class Pose:
+            def __init__(self, T):
+                self.T = np.asarray(T, np.float64)
+                self.data = torch.from_numpy(self.T.astype(np.float32)).reshape(1, 8)
+
+            def act(self, X):
+                return torch.from_numpy(syn.sim3_act(self.T, X.double().numpy()).astype(np.float32))
+
+        class Store:
+            def __init__(self, kf):
+                self.kfs = [kf]
+
+            def last_keyframe(self):
+                return self.kfs[-1]
+
+            def __len__(self):
+                return len(self.kfs)
+
+            def __setitem__(self, i, v):
+                self.kfs[i] = v
+
+        n, out = 80, {}
+        T_rel = np.array([0.02, -0.01, 0.03, 0.01, 0.02, -0.01, 0.9997, 1.01]); T_rel[3:7] /= np.linalg.norm(T_rel[3:7])
+        T_new = np.array([0.1, 0.2, 0.3, 0.0, 0.0, 0.0, 1.0, 1.0])
+        out["T_rel"], out["T_new"] = T_rel, T_new
+        g = torch.Generator().manual_seed(77)
+        cases = {"normal": dict(valid_p=0.9, idx="perm"), "skipped": dict(valid_p=0.02, idx="perm"),
+                 "new_kf_unique": dict(valid_p=0.9, idx="few"), "solver_fails": dict(valid_p=0.9, idx="perm", fail=True)}
+        for name, c in cases.items():
+            kf = Frame(0, torch.zeros(1, 3, 8, 10), None, None, None, Pose([0, 0, 0, 0, 0, 0, 1, 1]))
+            kf.update_pointmap(torch.randn(n, 3, generator=g) + 3, torch.rand(n, 1, generator=g) * 2 + 0.1)
+            fr = Frame(1, torch.zeros(1, 3, 8, 10), None, None, None, Pose([0, 0, 0, 0, 0, 0, 1, 1]))
+            idx = torch.randperm(n, generator=g)[None] if c["idx"] == "perm" else torch.randint(0, 5, (1, n), generator=g)
+            vm = (torch.rand(1, n, 1, generator=g) < c["valid_p"])
+            Xff, Xkf = torch.randn(n, 3, generator=g) + 3, torch.randn(n, 3, generator=g) + 3
+            Cff, Ckf = torch.rand(n, 1, generator=g) * 2 + 0.1, torch.rand(n, 1, generator=g) * 2 + 0.1
+            Qff, Qkf = torch.rand(n, 1, generator=g) * 4, torch.rand(n, 1, generator=g) * 4
+            store["match"] = (idx, vm, Xff, Cff, Qff, Xkf, Ckf, Qkf)
+            for k, v in zip(("idx", "vm", "Xff", "Cff", "Qff", "Xkf", "Ckf", "Qkf"), store["match"]):
+                out[f"{name}_{k}"] = v.numpy()
+            out[f"{name}_kfX0"], out[f"{name}_kfC0"] = kf.X_canon.numpy().copy(), kf.C.numpy().copy()
+            tr = trk.FrameTracker(None, Store(kf), "cpu")
+            seen = {}
+
+            def solver(Xf, Xk, T_WCf, T_WCk, Qk, valid, _c=c, _seen=seen):
+                _seen["Qk"], _seen["valid"], _seen["Xf"] = Qk.numpy().copy(), valid.numpy().copy(), Xf.numpy().copy()
+                if _c.get("fail"):
+                    raise RuntimeError("cholesky")
+                return Pose(T_new), Pose(T_rel)
+
+            tr.opt_pose_ray_dist_sim3 = solver
+            new_kf, info, skipped = tr.track(fr)
+            out[f"{name}_ret"] = np.array([bool(new_kf), bool(skipped), tr.idx_f2k is None])
+            for k, v in seen.items():
+                out[f"{name}_seen_{k}"] = v
+            if not skipped:
+                for k, v in zip(("Xk", "Ck", "Xf", "Cf", "Qkf", "Qff"), info):
+                    out[f"{name}_info_{k}"] = v.numpy()
+                out[f"{name}_kfN"] = np.array([tr.keyframes.kfs[0].N, tr.keyframes.kfs[0].N_updates])
+        np.savez_compressed(os.path.join(HERE, "track_logic.npz"), **out, **meta())
+        print("track_logic.npz", {k: out[f"{k}_ret"].tolist() for k in cases})
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+SECTIONS["track_logic"] = section_track_logic
 SECTIONS["factor_graph"] = section_factor_graph
 SECTIONS["frame"] = section_frame
 SECTIONS["quality"] = section_quality
