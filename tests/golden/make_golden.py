@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -645,6 +645,106 @@ def section_track_logic():
                 sys.modules[k] = v
 
 
+def fake_heads(code1, code2, H, W):
+    """Deterministic stand-in for decoder + heads: two result dicts that encode which (frame, other frame, head)
+    produced them.  Shared by this generator and tests/test_utils_wrappers_oracle.py."""
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    res = []
+    for head in (1, 2):
+        base = 100.0 * head + 10.0 * float(code1) + float(code2)
+        pts = torch.stack((base + yy, base + xx * 0.5, base + yy * xx * 0.01), -1)[None]
+        desc = torch.stack([base * 0.1 + yy * (k + 1) - xx for k in range(6)], -1)[None]
+        res.append(dict(pts3d=pts, conf=(base + xx)[None], desc=desc, desc_conf=(base - yy)[None]))
+    return res[0], res[1]
+
+
+def fake_match(X11, X21, D11, D21, idx_1_to_2_init=None):
+    """Stand-in for matching.match: index and validity derived from the inputs (so that argument order matters)."""
+    b, h, w = X21.shape[:3]
+    key = (X11.reshape(b, h * w, 3)[..., 0] * 7 + X21.reshape(b, h * w, 3)[..., 1] * 3 + D11.reshape(b, h * w, -1)[..., 0]
+           + 2 * D21.reshape(b, h * w, -1)[..., 1])
+    idx = (key.abs() * 13).long() % (h * w)
+    if idx_1_to_2_init is not None:
+        idx = (idx + idx_1_to_2_init) % (h * w)
+    return idx, ((key.long() % 3) != 0)[..., None]
+
+
+def section_utils_wrappers():
+    """mast3r_utils.py:34-231: the inference / matching wrappers (stack orders, reshapes, batch splitting,
+    downsample) of the reference module, run with its unimportable imports stubbed, a stand-in model and a
+    stand-in matching.match."""
+    import types
+
+    names = ("mast3r", "mast3r.utils", "mast3r.utils.path_to_dust3r", "dust3r", "dust3r.utils", "dust3r.utils.image",
+             "mast3r.model", "mast3r_slam", "mast3r_slam.retrieval_database", "mast3r_slam.config", "mast3r_slam.matching")
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        for n in ("mast3r", "mast3r.utils", "dust3r", "dust3r.utils", "mast3r_slam"):
+            m = types.ModuleType(n); m.__path__ = []
+            sys.modules[n] = m
+        sys.modules["mast3r.utils.path_to_dust3r"] = types.ModuleType("mast3r.utils.path_to_dust3r")
+        sys.modules["dust3r.utils.image"] = types.SimpleNamespace(ImgNorm=None)
+        sys.modules["mast3r.model"] = types.SimpleNamespace(AsymmetricMASt3R=object)
+        sys.modules["mast3r_slam.retrieval_database"] = types.SimpleNamespace(RetrievalDatabase=object)
+        ref_config = load_by_path("ref_config_uw", f"{REF}/mast3r_slam/config.py")
+        ref_config.config.update({"dataset": {"img_downsample": 1}})
+        sys.modules["mast3r_slam.config"] = ref_config
+        mm = types.ModuleType("mast3r_slam.matching"); mm.match = fake_match
+        sys.modules["mast3r_slam.matching"] = mm
+        sys.modules["mast3r_slam"].matching = mm
+        mu = load_by_path("ref_mast3r_utils", f"{REF}/mast3r_slam/mast3r_utils.py")
+        H, W = 8, 12
+
+        class Model:
+            def _encode_image(self, img, shape):
+                code = float(img.reshape(-1)[0])
+                return torch.full((1, 4, 3), code), torch.zeros(1, 4, 2, dtype=torch.long), None
+
+            def _decoder(self, f1, p1, f2, p2):
+                c1, c2 = float(f1.reshape(-1)[0]), float(f2.reshape(-1)[0])
+                return [torch.tensor([c1, c2])], [torch.tensor([c1, c2])]
+
+            def _downstream_head(self, k, toks, shape):
+                c1, c2 = float(toks[0][0]), float(toks[0][1])
+                return fake_heads(c1, c2, H, W)[k - 1]
+
+        class F:
+            def __init__(self, code):
+                self.img = torch.full((1, 3, H, W), float(code)); self.img_true_shape = torch.tensor([[H, W]])
+                self.feat = None; self.pos = None
+
+        model, out = Model(), {}
+        fa, fb, fc = F(1), F(2), F(3)
+        X, C = mu.mast3r_inference_mono(model, fa)
+        out["mono_X"], out["mono_C"] = X.numpy(), C.numpy()
+        for k, v in zip("XCDQ", mu.mast3r_symmetric_inference(model, fa, fb)):
+            out[f"sym_{k}"] = v.numpy()
+        for k, v in zip("XCDQ", mu.mast3r_asymmetric_inference(model, fb, fc)):
+            out[f"asym_{k}"] = v.numpy()
+        feat_i, feat_j = torch.cat((fa.feat, fb.feat)), torch.cat((fb.feat, fc.feat))
+        pos = torch.cat((fa.pos, fb.pos))
+        shp = [fa.img_true_shape, fb.img_true_shape]
+        for k, v in zip("XCDQ", mu.mast3r_decode_symmetric_batch(model, feat_i, pos, feat_j, pos, shp, shp)):
+            out[f"batch_{k}"] = v.numpy()
+        for k, v in enumerate(mu.mast3r_match_symmetric(model, feat_i, pos, feat_j, pos, shp, shp)):
+            out[f"msym_{k}"] = v.numpy()
+        init = torch.arange(H * W)[None] % 7
+        for k, v in enumerate(mu.mast3r_match_asymmetric(model, fa, fc, idx_i2j_init=init)):
+            out[f"masym_{k}"] = v.numpy()
+        ref_config.config["dataset"]["img_downsample"] = 2
+        for k, v in zip("XCDQ", mu.mast3r_asymmetric_inference(model, fb, fc)):
+            out[f"asym_ds2_{k}"] = v.numpy()
+        np.savez_compressed(os.path.join(HERE, "utils_wrappers.npz"), **out, **meta())
+        print("utils_wrappers.npz", {k: v.shape for k, v in out.items() if k.endswith("_X") or k.startswith("msym")})
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+SECTIONS["utils_wrappers"] = section_utils_wrappers
 SECTIONS["track_logic"] = section_track_logic
 SECTIONS["factor_graph"] = section_factor_graph
 SECTIONS["frame"] = section_frame
