@@ -201,7 +201,7 @@ class Pipeline:
             y0, x0 = 64 + 96 * b, 96 + 128 * b
             m = torch.zeros(H, W, dtype=torch.bool, device=dev)
             m[y0:y0 + 32, x0:x0 + 32] = True
-            self.refine_blocks.append(PatchBlock(0, b, m.reshape(-1)))
+            self.refine_blocks.append(PatchBlock(0, b, [], m.reshape(-1), 1.0, 1.0))
         # frontend pipeline: the encoder of frame f+1 runs on its own stream beside decode/match/track of frame f
         # multi-GPU: the backend thread is the only issuer of collectives while the clock runs (same order on every
         # rank); the main thread's barrier / all-reduce come after drain()

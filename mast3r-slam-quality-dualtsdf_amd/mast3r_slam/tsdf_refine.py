@@ -15,7 +15,11 @@ from mast3r_slam.config import config
 class PatchBlock:
     kf_id: int
     block_id: int
+    patch_indices: list        # [(py, px)] 16x16 patch coordinates
     pixel_mask: torch.Tensor   # (HW,) bool
+    depth_median: float
+    priority: float
+    depth_variance: float = 0.0
 
 
 class TSDFRefiner:
@@ -94,7 +98,7 @@ class TSDFRefiner:
         """tsdf_refine.py:667-835 (decision logic unchanged): returns (success, score)."""
         cfg = self.cfg
         kf = self.keyframes[block.kf_id]
-        start_version = self.versions.get(block.kf_id, 0)
+        start_version = self._version(block.kf_id)
         H, W = int(kf.img_shape[0, 0]), int(kf.img_shape[0, 1])
         X_canon = kf.X_canon.clone().to(self.device)
         C_flat = (kf.C.clone() if kf.C.ndim == 1 else kf.C[..., 0].clone()).to(self.device)
@@ -131,7 +135,7 @@ class TSDFRefiner:
         if not (hit_ratio >= float(cfg.get("min_hit_rate", 0.05)) and hit_count >= 1):
             self.stats["debug_info"]["hit_ratio_rejects"] += 1
             return False, hit_ratio
-        if self.versions.get(block.kf_id, 0) != start_version:   # optimistic version check (:790-794)
+        if self._version(block.kf_id) != start_version:   # optimistic version check (:790-794)
             return False, hit_ratio
         boost, cmax = float(cfg.get("confidence_boost", 0.08)), float(cfg.get("confidence_max", 1.3))
         if kf.C.ndim == 2:
@@ -142,7 +146,18 @@ class TSDFRefiner:
         gw = float(cfg.get("geometric_weight", 0.0))
         if gw > 0:
             kf.X_canon[mask_hits] = ((1 - gw) * X_canon + gw * X_refined)[mask_hits]
-        self.versions[block.kf_id] = start_version + 1
+        self._bump_version(block.kf_id, start_version + 1)
         return True, max(hit_ratio, geometric_gain)
+
+    # per-keyframe version counter: SharedKeyframes.version (frame.py:251) when the store has one, else a dict
+    def _version(self, kf_id):
+        v = getattr(self.keyframes, "version", None)
+        return int(v[kf_id]) if v is not None else self.versions.get(kf_id, 0)
+
+    def _bump_version(self, kf_id, value):
+        v = getattr(self.keyframes, "version", None)
+        if v is not None:
+            v[kf_id] = value
+        self.versions[kf_id] = value
 
     refine_block = _refine_block_enhanced

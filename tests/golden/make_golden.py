@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -744,6 +744,77 @@ def section_utils_wrappers():
                 sys.modules[k] = v
 
 
+def section_refine_block():
+    """TSDFRefiner._refine_block_enhanced (tsdf_refine.py:667-835) on a one-keyframe store, identity pose: the gates
+    (valid pixels, ROI, voxel count, displacement, hit ratio), the confidence boost / clamp and the version counter.
+    torch.manual_seed(123) right before each call fixes the <= 100 ray-cast pixels (torch.randperm, :965)."""
+    import contextlib
+    import io
+    import threading
+
+    from mast3r_slam import synthetic
+
+    tr = load_by_path("ref_tsdf_refine_rb", f"{REF}/mast3r_slam/tsdf_refine.py")
+    base = dict(enabled=True, window_size=5, voxel_size=0.02, trunc_dist=0.08, max_grid_dim=64, roi_size=0.4, ray_samples=64,
+                max_displacement=0.015, min_weight_threshold=0.01, confidence_boost=0.08, confidence_max=1.3, min_hit_rate=0.05,
+                max_rois_per_kf=3, min_confidence=0.2)
+
+    class Pose:
+        def clone(self):
+            return self
+
+        def matrix(self):
+            return torch.eye(4)[None]
+
+        def act(self, X):
+            return X.clone()
+
+    H, W = 48, 64
+    Tcam = synthetic.camera_pose(2)
+    rng = np.random.default_rng(4)
+    X = (synthetic.render_pointmap(Tcam, H, W).reshape(-1, 3) + rng.normal(0, 0.003, (H * W, 3))).astype(np.float32)
+    C = rng.uniform(0.1, 1.2, (H * W, 1)).astype(np.float32)
+    C[:16 * W] = 0.01                                             # the top band is unusable
+    out = dict(X=X, C=C, H=H, W=W)
+
+    def mask_of(y0, x0):
+        m = np.zeros((H, W), bool); m[y0:y0 + 16, x0:x0 + 16] = True
+        return m.reshape(-1)
+
+    cases = {"accepted": (dict(min_hit_rate=0.02), mask_of(16, 24)), "hit_ratio_reject": (dict(), mask_of(16, 24)),
+             "too_few_valid": (dict(), mask_of(0, 8))}
+    for name, (over, mask) in cases.items():
+        class KF:
+            pass
+
+        kf = KF()
+        kf.img_shape = torch.tensor([[H, W]]); kf.X_canon = torch.from_numpy(X.copy()); kf.C = torch.from_numpy(C.copy())
+        kf.K = torch.eye(3); kf.T_WC = Pose()
+
+        class Store:
+            lock = threading.RLock()
+            version = torch.zeros(4, dtype=torch.long)
+
+            def __getitem__(self, i):
+                return kf
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = tr.TSDFRefiner(dict(base, **over), Store(), None, "cpu")
+            block = tr.PatchBlock(0, 7, [], torch.from_numpy(mask), 1.0, 1.0)
+            torch.manual_seed(123)
+            ok, score = ref._refine_block_enhanced(block)
+        out[f"{name}_mask"] = mask
+        out[f"{name}_ret"] = np.array([float(ok), float(score)])
+        out[f"{name}_C_after"] = kf.C.numpy().copy()
+        out[f"{name}_version"] = ref.keyframes.version.numpy().copy()
+        d = ref.stats["debug_info"]
+        out[f"{name}_stats"] = np.array([d["tsdf_constructions"], d["surface_extractions"], d["displacement_rejects"], d["hit_ratio_rejects"]])
+        out[f"{name}_min_hit_rate"] = np.array(dict(base, **over)["min_hit_rate"])
+        print(name, bool(ok), round(float(score), 4), "changed C:", int((kf.C.numpy() != C).sum()), out[f"{name}_stats"].tolist())
+    np.savez_compressed(os.path.join(HERE, "refine_block.npz"), **out, **meta())
+
+
+SECTIONS["refine_block"] = section_refine_block
 SECTIONS["utils_wrappers"] = section_utils_wrappers
 SECTIONS["track_logic"] = section_track_logic
 SECTIONS["factor_graph"] = section_factor_graph

@@ -83,7 +83,7 @@ def test_refine_block_decision(device):
     mask = np.zeros(H * W, bool)
     mask[(ys * W + xs).reshape(-1)] = True
     C0 = kf.C.clone()
-    ok, score = ref._refine_block_enhanced(PatchBlock(0, 0, t(mask)), order=torch.arange(100))
+    ok, score = ref._refine_block_enhanced(PatchBlock(0, 0, [], t(mask), 1.0, 1.0), order=torch.arange(100))
     changed = (kf.C != C0).reshape(-1)
     if ok:
         assert changed.sum() >= 13 and not changed[~t(mask)].any()      # >= 5 % of 256 pixels hit
@@ -92,3 +92,36 @@ def test_refine_block_decision(device):
     else:
         assert not changed.any()
     assert ref.stats["debug_info"]["tsdf_constructions"] == 1
+
+
+@pytest.mark.parametrize("case", ["accepted", "hit_ratio_reject", "too_few_valid"])
+def test_refine_block_vs_reference(device, golden_dir, case):
+    """_refine_block_enhanced against the reference class run on the same one-keyframe store (fixture
+    refine_block.npz, tsdf_refine.py:667-835): return value, boosted confidences, version counter and
+    the debug counters.  The ray-cast subset is the reference's torch.manual_seed(123) randperm."""
+    from lietorch_hip import Sim3
+    from mast3r_slam.frame import Frame, KeyframeStore
+    from mast3r_slam.tsdf_refine import PatchBlock, TSDFRefiner
+
+    fx = np.load(os.path.join(golden_dir, "refine_block.npz"))
+    H, W = int(fx["H"]), int(fx["W"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    kf = Frame(0, torch.zeros(1, 3, H, W, device=device), torch.tensor([[H, W]]), torch.tensor([[H, W]]), None,
+               Sim3.Identity(1, device=device), t(fx["X"]), t(fx["C"]))
+    kf.N = 1
+    store = KeyframeStore()
+    store.append(kf)
+    store.version = torch.zeros(4, dtype=torch.long)
+    ref = TSDFRefiner(dict(CFG, min_hit_rate=float(fx[f"{case}_min_hit_rate"])), store, None, device)
+    mask = fx[f"{case}_mask"]
+    torch.manual_seed(123)
+    order = torch.randperm(int(mask.sum()))[:100]
+    ok, score = ref._refine_block_enhanced(PatchBlock(0, 7, [], t(mask), 1.0, 1.0), order=order)
+    assert float(ok) == fx[f"{case}_ret"][0]
+    np.testing.assert_allclose(score, fx[f"{case}_ret"][1], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(kf.C.cpu().numpy(), fx[f"{case}_C_after"], rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(kf.C.cpu().numpy() != fx["C"], fx[f"{case}_C_after"] != fx["C"])
+    np.testing.assert_array_equal(store.version.numpy(), fx[f"{case}_version"])
+    d = ref.stats["debug_info"]
+    got = [d["tsdf_constructions"], d["surface_extractions"], d["displacement_rejects"], d["hit_ratio_rejects"]]
+    assert got == fx[f"{case}_stats"].tolist()
