@@ -60,6 +60,10 @@ def parse():
                     help="run the keyframe backend inline in the tracking loop instead of on its own thread + stream")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="encode each frame inside its own step instead of one frame ahead on a second stream")
+    ap.add_argument("--frame-group", type=int, default=4,
+                    help="frames whose network stages run in one batch call: the encoder runs this many frames ahead, the "
+                         "pair decode speculates that the keyframe stays (discarded and redone after a keyframe change); "
+                         "matching and tracking stay strictly per frame.  1 = every stage one frame at a time")
     ap.add_argument("--depth-scale", type=float, default=1.0, help="debug: <1 shrinks the network depth")
     return ap.parse_args()
 
@@ -207,7 +211,13 @@ class Pipeline:
         # rank); the main thread's barrier / all-reduce come after drain()
         self.worker = None if args.no_backend_thread else BackendWorker(dev)
         self.enc_stream = torch.cuda.Stream(device=dev)
-        self.next_feat, self.enc_done = None, None
+        self.B = 1 if args.no_pipeline else max(1, args.frame_group)
+        self.spec_waste = self.B // 2            # ceil((B-1)/2): expected frames decoded in vain per keyframe change
+        self.t = 0                               # position in the stream (the step index restarts per phase)
+        self.enc, self.enc_hi = {}, 0            # encoder batches in flight / done: first frame -> (feat, event)
+        self.dec_hi, self.dec_epoch, self.kf_epoch = 0, -1, 0
+        self.kf_feat_b = {n: self.kf_feat.expand(n, -1, -1).contiguous() for n in range(1, self.B + 1)}
+        self.img_b = {}
         self.net_ms = 0.0
         self.net_calls = 0
         self.timing = False
@@ -230,33 +240,62 @@ class Pipeline:
 
         a = self.args
         c = self.cfg
-        img = self.frames[f % len(self.frames)]
         pr = self.pairs[f % len(self.pairs)]
+        t, B = self.t, self.B
+        self.t += 1
         # ---- tracking ---------------------------------------------------------------------------
         main = torch.cuda.current_stream(self.dev)
-        if a.no_pipeline:
-            feat = self._net(lambda: self.model._encode_image(img)[0])
-        else:
-            if self.next_feat is None:   # very first frame: nothing was prefetched
-                feat = self.model._encode_image(img)[0]
-            else:
-                main.wait_event(self.enc_done)
-                feat = self.next_feat
-                feat.record_stream(main)
-            with torch.cuda.stream(self.enc_stream):   # frame f+1 (its image does not depend on frame f's pose)
-                self.next_feat = self._net(lambda: self.model._encode_image(self.frames[(f + 1) % len(self.frames)])[0])
-                self.enc_done = torch.cuda.Event()
-                self.enc_done.record()
-        self._net(lambda: self.model.decode_pair(feat, self.kf_feat, H, W))
+        if t >= self.dec_hi or self.dec_epoch != self.kf_epoch:
+            # frames t .. t+B-1 against the current keyframe in one call; their features were encoded >= B steps ago
+            # on the encoder stream, which now runs the NEXT groups beside this one's decode / match / track
+            self._encode_ahead(t)
+            feats = self._group_feats(t, B, main)
+            self._net(lambda: self.model.decode_pair(feats, self.kf_feat_b[B], H, W))
+            self.dec_hi, self.dec_epoch = t + B, self.kf_epoch
         idx, valid = matching.match(pr["X11"], pr["X21"], pr["D11"], pr["D21"])
         self.tracker.opt_pose_ray_dist_sim3(pr["Xf"], pr["Xk"], Sim3(pr["T_WCf"]), Sim3(pr["T_WCk"]), pr["Qk"],
                                             valid[0], idx=idx[0])
         # ---- keyframe / backend -------------------------------------------------------------------
         if f % a.kf_every == 0:
+            # frame f became a keyframe: what was decoded ahead against the old one is void.  With a fixed keyframe
+            # period the groups realign behind every keyframe and nothing would ever be wasted, so the EXPECTED loss
+            # of a keyframe at a random position in its group, ceil((B-1)/2) frames, is charged explicitly
+            self.kf_epoch += 1
+            if self.spec_waste:
+                self._net(lambda: self.model.decode_pair(self.kf_feat_b[self.spec_waste], self.kf_feat_b[self.spec_waste], H, W))
             if self.worker is not None:
                 self.worker.q.put(self.backend)
             else:
                 self.backend()
+
+    def _encode_ahead(self, t):
+        """Keep the encoder 2 groups ahead of frame t (batches of B frames, aligned at multiples of B)."""
+        B = self.B
+        while self.enc_hi < t + (B if self.args.no_pipeline else 2 * B):
+            s0 = self.enc_hi
+            key = s0 % len(self.frames)
+            if key not in self.img_b:
+                self.img_b[key] = torch.cat([self.frames[(s0 + k) % len(self.frames)] for k in range(B)])
+            with torch.cuda.stream(torch.cuda.current_stream(self.dev) if self.args.no_pipeline else self.enc_stream):
+                feat = self._net(lambda: self.model._encode_image(self.img_b[key])[0])
+                ev = torch.cuda.Event()
+                ev.record()
+            self.enc[s0] = (feat, ev)
+            self.enc_hi = s0 + B
+
+    def _group_feats(self, t, n, main):
+        B, parts, k = self.B, [], t
+        while k < t + n:
+            s0 = (k // B) * B
+            feat, ev = self.enc[s0]
+            main.wait_event(ev)
+            feat.record_stream(main)
+            e = min(t + n, s0 + B)
+            parts.append(feat[k - s0:e - s0])
+            k = e
+        for s0 in [q for q in self.enc if q + B <= t]:
+            del self.enc[s0]
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
 
     def backend(self):
         from lietorch_hip import Sim3
@@ -301,12 +340,14 @@ class Pipeline:
         for blk in self.refine_blocks:
             self.refiner.refine_block(blk)
 
-    def network_probe(self, frames=6):
-        """Kernel-quality figure for the roofline object: the network stages of `frames` tracked frames and
-        one keyframe batch run back to back WITHOUT the frontend overlap, event-timed on their stream.
-        Returns (GFLOP, ms)."""
-        a = self.args
+    def network_probe(self, frames=8):
+        """Kernel-quality figure for the roofline object: the network stages of `frames` tracked frames (in the
+        pipeline's groups of B) and one keyframe batch run back to back WITHOUT the frontend overlap, event-timed on
+        their stream.  Returns (GFLOP, ms)."""
+        a, B = self.args, self.B
         ts = torch.tensor([[H, W]])
+        groups = max(1, frames // B)
+        img = torch.cat([self.frames[k % len(self.frames)] for k in range(B)])
         evs = []
         def timed(fn):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -316,13 +357,13 @@ class Pipeline:
         for rep in range(2):   # pass 0 untimed: this stream's arenas are allocated on first use
             evs.clear()
             torch.cuda.synchronize()
-            for k in range(frames if rep else 1):
-                feat = timed(lambda: self.model._encode_image(self.frames[k % len(self.frames)], ts)[0])
-                timed(lambda: self.model.decode_pair(feat, self.kf_feat, H, W))
+            for k in range(groups if rep else 1):
+                feat = timed(lambda: self.model._encode_image(img, ts)[0])
+                timed(lambda: self.model.decode_pair(feat, self.kf_feat_b[B], H, W))
             timed(lambda: self.model.decode_pair(self.feat_ij, self.feat_ji, H, W))
             torch.cuda.synchronize()
         ms = sum(e0.elapsed_time(e1) for e0, e1 in evs)
-        return frames * self.flop_scale * GF_TRACK + a.edges_per_kf * GF_EDGE, ms
+        return groups * B * self.flop_scale * GF_TRACK + a.edges_per_kf * GF_EDGE, ms
 
     def dominant_kernel_probe(self, iters=50):
         """The kernel with the largest share of the step (profiles/r01_bench_kernel_stats.csv): the 64x64-tile
@@ -498,7 +539,11 @@ def main():
                        "weights": "random-init ViT-L/12+12 MASt3R architecture (no checkpoint offline)",
                        "backend": "inline" if pipe.worker is None else "own host thread + stream (as the reference's backend process)",
                        "frontend": "eager launches" + (", HIP graphs" if args.graphs else "") +
-                                   ("" if args.no_pipeline else ", encoder of frame f+1 overlapped with frame f on a second stream"),
+                                   ("" if args.no_pipeline else ", encoder runs ahead on a second stream") +
+                                   (f", network stages in groups of {pipe.B} frames (encoder ahead; pair decode speculative on the "
+                                    f"keyframe, {pipe.spec_waste} discarded frame decodes charged per keyframe); "
+                                    "matching + tracking per frame" if pipe.B > 1 else ""),
+                       "frame_group": pipe.B,
                        "parallelism": f"streams x{world}, GN edges + TSDF voxels sharded"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS,

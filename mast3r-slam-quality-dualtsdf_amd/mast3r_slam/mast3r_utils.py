@@ -102,8 +102,46 @@ def mast3r_match_symmetric(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j
 
 
 @torch.inference_mode()
+def encode_frames(model, frames):
+    """Frame-group extension (no reference counterpart; the reference encodes lazily, one frame per call,
+    mast3r_utils.py:186-193): ONE batch encoder call fills .feat / .pos of every frame that has none.  The
+    encoder does not depend on any pose, so a sequence reader may run it any number of frames ahead; rows of a
+    batch are computed exactly as in a batch of one (tests/test_mast3r_gpu.py::test_frame_group…)."""
+    todo = [f for f in frames if f.feat is None]
+    if not todo:
+        return
+    feat, pos, _ = model._encode_image(torch.cat([f.img for f in todo]), todo[0].img_true_shape)
+    for k, f in enumerate(todo):
+        f.feat, f.pos = feat[k:k + 1], pos[k:k + 1]
+
+
+@torch.inference_mode()
+def mast3r_asymmetric_inference_group(model, frames, keyframe):
+    """Frame-group extension: the two-view forward of `frames` (consecutive, not yet tracked) against the current
+    keyframe in ONE batch call.  Each frame keeps its (X, C, D, Q) tagged with the keyframe it was decoded against;
+    mast3r_asymmetric_inference(frame, keyframe) consumes it if the keyframe is still the same one and recomputes
+    otherwise (speculation: a frame of the group may become a keyframe, which invalidates the rest)."""
+    frames = list(frames)
+    encode_frames(model, frames)
+    _ensure_feat(model, keyframe)
+    B = len(frames)
+    feat_i = torch.cat([f.feat for f in frames])
+    res11, res21 = decoder(model, feat_i, keyframe.feat.expand(B, -1, -1).contiguous(), None, None,
+                           frames[0].img_true_shape, keyframe.img_true_shape)
+    for k, f in enumerate(frames):
+        pick = lambda key: torch.stack((res11[key][k], res21[key][k]))
+        f.decoded = (int(keyframe.frame_id), downsample(pick("pts3d"), pick("conf"), pick("desc"), pick("desc_conf")))
+
+
+@torch.inference_mode()
 def mast3r_asymmetric_inference(model, frame_i, frame_j):
-    """mast3r_utils.py:183-206."""
+    """mast3r_utils.py:183-206.  A result left by mast3r_asymmetric_inference_group for this very pair is used
+    once instead of being recomputed."""
+    stash = getattr(frame_i, "decoded", None)
+    if stash is not None:
+        frame_i.decoded = None
+        if stash[0] == int(frame_j.frame_id):   # a keyframe's features never change once encoded
+            return stash[1]
     _ensure_feat(model, frame_i)
     _ensure_feat(model, frame_j)
     res11, res21 = decoder(model, frame_i.feat, frame_j.feat, frame_i.pos, frame_j.pos, frame_i.img_true_shape,

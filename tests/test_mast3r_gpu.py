@@ -128,6 +128,48 @@ def test_mast3r_utils_wrappers(device):
     assert torch.equal(X[:, :1], X1)
 
 
+def test_frame_group_matches_per_frame(device):
+    """encode_frames / mast3r_asymmetric_inference_group: a group of frames through ONE encoder and ONE decoder call
+    gives bit-identical per-frame results to the reference's one-frame-at-a-time calls; a stashed result is used
+    once, and only for the keyframe it was decoded against."""
+    from mast3r_slam import mast3r_utils as mu
+    from mast3r_slam.frame import Frame
+
+    cfg = R.Mast3rConfig(enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=128, dec_depth=12, dec_heads=2)
+    sd, model = _model(cfg, 9, device)
+    H, W = 64, 96
+    g = torch.Generator().manual_seed(3)
+    imgs = [(torch.rand(1, 3, H, W, generator=g) * 2 - 1).to(device) for _ in range(5)]
+    mk = lambda i: Frame(i, imgs[i], torch.tensor([[H, W]]), torch.tensor([[H, W]]), None)
+    kf, kf2 = mk(0), mk(4)
+    single = []
+    for i in (1, 2, 3):
+        f = mk(i)
+        single.append((mu.mast3r_asymmetric_inference(model, f, kf), f.feat.clone()))
+    group = [mk(i) for i in (1, 2, 3)]
+    kfg = mk(0)
+    mu.mast3r_asymmetric_inference_group(model, group, kfg)
+    calls = []
+    real = model.decode_pair
+    model.decode_pair = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    for f, (ref, feat) in zip(group, single):
+        assert torch.equal(f.feat, feat)
+        out = mu.mast3r_asymmetric_inference(model, f, kfg)
+        assert f.decoded is None
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+    assert not calls                               # all three came from the group call
+    mu.mast3r_asymmetric_inference(model, group[0], kfg)
+    assert len(calls) == 1                         # the stash is used once
+    mu.mast3r_asymmetric_inference_group(model, group[1:], kfg)
+    out = mu.mast3r_asymmetric_inference(model, group[1], kf2)   # the keyframe changed: recomputed against the new one
+    assert len(calls) == 3
+    ref = mu.mast3r_asymmetric_inference(model, mk(2), mk(4))
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    model.decode_pair = real
+
+
 def test_graph_replay_matches_eager(device):
     """use_graphs=True replays captured HIP graphs (two-stream decoder included); results are bit-identical
     to the eager launches and stay valid after later calls (fresh output tensors)."""
