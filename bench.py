@@ -216,7 +216,8 @@ class Pipeline:
         self.t = 0                               # position in the stream (the step index restarts per phase)
         self.enc, self.enc_hi = {}, 0            # encoder batches in flight / done: first frame -> (feat, event)
         self.dec_hi, self.dec_epoch, self.kf_epoch = 0, -1, 0
-        self.kf_feat_b = {n: self.kf_feat.expand(n, -1, -1).contiguous() for n in range(1, self.B + 1)}
+        self.void_rows = 0                       # rows of the next group call that stand for frames decoded in vain
+        self.kf_feat_b = {n: self.kf_feat.expand(n, -1, -1).contiguous() for n in range(1, self.B + self.spec_waste + 1)}
         self.img_b = {}
         self.net_ms = 0.0
         self.net_calls = 0
@@ -250,19 +251,22 @@ class Pipeline:
             # on the encoder stream, which now runs the NEXT groups beside this one's decode / match / track
             self._encode_ahead(t)
             feats = self._group_feats(t, B, main)
-            self._net(lambda: self.model.decode_pair(feats, self.kf_feat_b[B], H, W))
+            if self.void_rows:   # see the keyframe branch below
+                feats = torch.cat((feats, feats[:self.void_rows]))
+                self.void_rows = 0
+            self._net(lambda: self.model.decode_pair(feats, self.kf_feat_b[feats.shape[0]], H, W))
             self.dec_hi, self.dec_epoch = t + B, self.kf_epoch
         idx, valid = matching.match(pr["X11"], pr["X21"], pr["D11"], pr["D21"])
         self.tracker.opt_pose_ray_dist_sim3(pr["Xf"], pr["Xk"], Sim3(pr["T_WCf"]), Sim3(pr["T_WCk"]), pr["Qk"],
                                             valid[0], idx=idx[0])
         # ---- keyframe / backend -------------------------------------------------------------------
         if f % a.kf_every == 0:
-            # frame f became a keyframe: what was decoded ahead against the old one is void.  With a fixed keyframe
-            # period the groups realign behind every keyframe and nothing would ever be wasted, so the EXPECTED loss
-            # of a keyframe at a random position in its group, ceil((B-1)/2) frames, is charged explicitly
+            # frame f became a keyframe: what was decoded ahead against the old one is void and the next group starts
+            # right behind it.  With a fixed keyframe period the groups realign behind every keyframe and nothing would
+            # ever be decoded in vain, so the EXPECTED loss for a keyframe at a random position of its group,
+            # ceil((B-1)/2) rows of a group call, is charged explicitly: the next group call carries that many extra rows
             self.kf_epoch += 1
-            if self.spec_waste:
-                self._net(lambda: self.model.decode_pair(self.kf_feat_b[self.spec_waste], self.kf_feat_b[self.spec_waste], H, W))
+            self.void_rows = self.spec_waste
             if self.worker is not None:
                 self.worker.q.put(self.backend)
             else:
@@ -541,7 +545,7 @@ def main():
                        "frontend": "eager launches" + (", HIP graphs" if args.graphs else "") +
                                    ("" if args.no_pipeline else ", encoder runs ahead on a second stream") +
                                    (f", network stages in groups of {pipe.B} frames (encoder ahead; pair decode speculative on the "
-                                    f"keyframe, {pipe.spec_waste} discarded frame decodes charged per keyframe); "
+                                    f"keyframe, {pipe.spec_waste} discarded rows charged per keyframe); "
                                     "matching + tracking per frame" if pipe.B > 1 else ""),
                        "frame_group": pipe.B,
                        "parallelism": f"streams x{world}, GN edges + TSDF voxels sharded"},

@@ -128,6 +128,9 @@ class KeyframeStore:
     def append(self, frame):
         self._kfs.append(frame)
 
+    def pop_last(self):
+        self._kfs.pop()
+
     def last_keyframe(self):
         return self._kfs[-1] if self._kfs else None
 

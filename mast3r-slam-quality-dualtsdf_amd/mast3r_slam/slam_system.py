@@ -1,0 +1,202 @@
+"""the reference's process model as ONE process.
+
+main.py runs the tracking frontend (main.py:325-446) and the backend (run_backend, main.py:73-163; relocalization,
+main.py:28-71) as two processes that share keyframes through CUDA-IPC buffers, manager locks and 10 ms polling.
+`SlamSystem` is the same state machine (Mode.INIT / TRACKING / RELOC, the same calls in the same order) in one
+process with the semantics of the reference's `single_thread: True` evaluation configs (the backend task of a
+keyframe is finished before the next frame is tracked, main.py:391-395), plus two things the split made impossible:
+
+* **frame groups** (`frame_group` = B > 1): the encoder runs B frames ahead on its own stream and the two-view
+  forward of the next B frames against the current keyframe is ONE batch call
+  (mast3r_utils.mast3r_asymmetric_inference_group).  Matching and tracking stay strictly per frame, in order.  The
+  group decode speculates that the keyframe stays: when a frame of the group becomes a keyframe (or tracking falls
+  into RELOC) the rest of the group is decoded again against the new keyframe.  Rows of a batch are computed exactly as
+  a batch of one, so the trajectory is bit-identical to B = 1 (tests/test_slam_system_gpu.py).
+* the keyframe store is whatever the caller passes: `KeyframeStore` (unbounded) or the `SharedKeyframes` mirror.
+
+Retrieval (retrieval_database.py, ASMK) is not available offline; `retriever` is any object with the reference's
+`update(frame, add_after_query, k, min_thresh) -> [keyframe ids]`.  The default stand-in proposes no loop-closure edges
+and offers the most recent keyframes as relocalisation candidates."""
+import torch
+
+from lietorch_hip import Sim3
+from mast3r_slam import mast3r_utils as mu
+from mast3r_slam.config import config
+from mast3r_slam.frame import KeyframeStore, Mode
+from mast3r_slam.global_opt import FactorGraph
+from mast3r_slam.tracker import FrameTracker
+
+
+class RecentKeyframes:
+    """Stand-in for RetrievalDatabase.update: no loop-closure proposals for the graph (add_after_query=True), the
+    last `k` keyframes as relocalisation candidates (add_after_query=False)."""
+
+    def __init__(self, keyframes, k=1):
+        self.keyframes, self.k = keyframes, k
+
+    def update(self, frame, add_after_query=True, k=3, min_thresh=0.0):
+        if add_after_query:
+            return []
+        n = len(self.keyframes)
+        return list(range(max(0, n - self.k), n))[::-1]
+
+
+class SlamSystem:
+    def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None):
+        self.model, self.device, self.K = model, torch.device(device), K
+        self.keyframes = KeyframeStore() if keyframes is None else keyframes
+        self.tracker = FrameTracker(model, self.keyframes, device)
+        self.factor_graph = FactorGraph(model, self.keyframes, K, device)
+        self.retriever = RecentKeyframes(self.keyframes) if retriever is None else retriever
+        self.tsdf_manager = None
+        if tsdf_global_cfg is not None and tsdf_global_cfg.get("enabled", False):   # main.py:78-88
+            from mast3r_slam.tsdf import TSDFGlobalManager
+
+            self.tsdf_manager = TSDFGlobalManager(self.keyframes, tsdf_global_cfg, config.get("use_calib", False), device)
+            self.tsdf_manager.start()
+        self.mode = Mode.INIT
+        self.last_T = None
+        self.frame_group = max(1, int(frame_group))
+        self.enc_stream = torch.cuda.Stream(device=self.device) if self.frame_group > 1 else None
+        self._enc_hi = 0
+        self.stats = dict(frames=0, keyframes=0, group_calls=0, decoded_rows=0, void_rows=0, relocalised=0)
+
+    # ------------------------------------------------------------------ frontend (main.py:325-446)
+    def run(self, frames):
+        """Track a sequence of Frame objects (frame.create_frame) in order; returns the per-frame results of step()."""
+        out = []
+        for i in range(len(frames)):
+            if self.frame_group > 1:
+                self._look_ahead(frames, i)
+            out.append(self.step(frames[i]))
+        return out
+
+    def step(self, frame):
+        """One iteration of the main loop for an already created frame -> dict(mode, new_kf, try_reloc)."""
+        self._wait_encoded(frame)
+        if self.last_T is not None:                     # "last camera pose for the frame" (main.py:351-356)
+            frame.T_WC = Sim3(self.last_T.data.clone())
+        self.stats["frames"] += 1
+        add_new_kf = try_reloc = False
+        mode = self.mode
+        if mode == Mode.INIT:                           # main.py:359-367
+            X_init, C_init = mu.mast3r_inference_mono(self.model, frame)
+            frame.update_pointmap(X_init, C_init)
+            self.keyframes.append(frame)
+            self.stats["keyframes"] += 1
+            self.mode = Mode.TRACKING
+            self.last_T = frame.T_WC
+            self._backend(len(self.keyframes) - 1)
+            return dict(mode=mode, new_kf=True, try_reloc=False)
+        if mode == Mode.TRACKING:                       # main.py:369-373
+            add_new_kf, _, try_reloc = self.tracker.track(frame)
+            if try_reloc:
+                self.mode = Mode.RELOC
+            self.last_T = frame.T_WC
+        elif mode == Mode.RELOC:                        # main.py:375-385
+            X, C = mu.mast3r_inference_mono(self.model, frame)
+            frame.update_pointmap(X, C)
+            self.last_T = frame.T_WC
+            if self._relocalization(frame):
+                self.mode = Mode.TRACKING
+                self.stats["relocalised"] += 1
+        else:
+            raise Exception("Invalid mode")
+        if add_new_kf:                                  # main.py:387-395
+            self.keyframes.append(frame)
+            self.stats["keyframes"] += 1
+            self._backend(len(self.keyframes) - 1)
+        return dict(mode=mode, new_kf=bool(add_new_kf), try_reloc=bool(try_reloc))
+
+    def shutdown(self):
+        if self.tsdf_manager is not None:
+            self.tsdf_manager.shutdown()
+
+    # ------------------------------------------------------------------ frame groups
+    def _wait_encoded(self, frame):
+        ev = getattr(frame, "enc_event", None)
+        if ev is not None:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(ev)
+            frame.feat.record_stream(main)
+            frame.pos.record_stream(main)
+            frame.enc_event = None
+
+    def _look_ahead(self, frames, i):
+        B, n = self.frame_group, len(frames)
+        main = torch.cuda.current_stream(self.device)
+        while self._enc_hi < min(n, i + 2 * B):          # encoder: groups of B, up to two groups ahead of frame i
+            grp = [frames[k] for k in range(self._enc_hi, min(n, self._enc_hi + B))]
+            self.enc_stream.wait_stream(main)            # the images were produced on the caller's stream
+            with torch.cuda.stream(self.enc_stream):
+                mu.encode_frames(self.model, grp)
+                ev = torch.cuda.Event()
+                ev.record()
+            for f in grp:
+                f.enc_event = ev
+            self._enc_hi += len(grp)
+        if self.mode != Mode.TRACKING:
+            return
+        keyframe = self.keyframes.last_keyframe()
+        stash = getattr(frames[i], "decoded", None)
+        if stash is not None and stash[0] == int(keyframe.frame_id):
+            return
+        window = [frames[k] for k in range(i, min(n, i + B))]
+        for f in window:
+            self._wait_encoded(f)
+            if getattr(f, "decoded", None) is not None:  # decoded against a keyframe that has been replaced since
+                self.stats["void_rows"] += 1
+        mu.mast3r_asymmetric_inference_group(self.model, window, keyframe)
+        self.stats["group_calls"] += 1
+        self.stats["decoded_rows"] += len(window)
+
+    # ------------------------------------------------------------------ backend (main.py:73-163, 28-71)
+    def _backend(self, idx):
+        """The body of run_backend's loop for the keyframe `idx` (graph construction, global GN, TSDF hook)."""
+        kf_idx = []
+        n_consec = 1
+        for j in range(min(n_consec, idx)):
+            kf_idx.append(idx - 1 - j)
+        frame = self.keyframes[idx]
+        retrieval_inds = self.retriever.update(frame, add_after_query=True, k=config["retrieval"]["k"],
+                                               min_thresh=config["retrieval"]["min_thresh"])
+        kf_idx += retrieval_inds
+        kf_idx = set(kf_idx)
+        kf_idx.discard(idx)
+        kf_idx = list(kf_idx)
+        frame_idx = [idx] * len(kf_idx)
+        if kf_idx:
+            self.factor_graph.add_factors(kf_idx, frame_idx, config["local_opt"]["min_match_frac"])
+        self._solve()
+        if self.tsdf_manager is not None:
+            self.tsdf_manager.on_after_backend_solve(self.factor_graph)
+
+    def _solve(self):
+        if config["use_calib"]:
+            self.factor_graph.solve_GN_calib()
+        else:
+            self.factor_graph.solve_GN_rays()
+
+    def _relocalization(self, frame):
+        """main.py:28-71."""
+        kf_idx = list(self.retriever.update(frame, add_after_query=False, k=config["retrieval"]["k"],
+                                            min_thresh=config["retrieval"]["min_thresh"]))
+        success = False
+        if kf_idx:
+            self.keyframes.append(frame)
+            n_kf = len(self.keyframes)
+            frame_idx = [n_kf - 1] * len(kf_idx)
+            if self.factor_graph.add_factors(frame_idx, kf_idx, config["reloc"]["min_match_frac"],
+                                             is_reloc=config["reloc"]["strict"]):
+                self.retriever.update(frame, add_after_query=True, k=config["retrieval"]["k"],
+                                      min_thresh=config["retrieval"]["min_thresh"])
+                success = True
+                kf = self.keyframes[n_kf - 1]
+                kf.T_WC = Sim3(self.keyframes[kf_idx[0]].T_WC.data.clone())
+                self.keyframes[n_kf - 1] = kf
+                self.stats["keyframes"] += 1
+            else:
+                self.keyframes.pop_last()
+        if success:
+            self._solve()
+        return success

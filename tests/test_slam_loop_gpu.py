@@ -63,7 +63,7 @@ def test_trajectory_is_recovered(device):
     graph = FactorGraph(model, keyframes, device=device)
     vol = TSDFVolume(0.03, 0.12, capacity=1 << 18, device=device)
     tcfg = dict(config["tsdf_global"], pre_icp_iters=0)   # fuse only: the reference's TSDF-ICP step is not a contraction
-    integ = TSDFGlobalIntegrator(vol, TSDFPoseOptimizer(vol, keyframes, tcfg, False, device), keyframes, tcfg)
+    integ = TSDFGlobalIntegrator(vol, keyframes, tcfg, TSDFPoseOptimizer(vol, keyframes, tcfg, False, device))
     ks = list(range(0, 40, 4))                      # ten frames along the room trajectory
     T0 = synthetic.camera_pose(ks[0])
     last_T = Sim3.Identity(1, device=device)

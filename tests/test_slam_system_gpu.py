@@ -1,0 +1,130 @@
+"""SlamSystem (the reference's frontend loop + backend in one process, main.py:28-163,325-446) on the
+procedural room, WITHOUT the network: a stand-in model hands out the two-view geometry.  Checks the state machine
+(INIT -> TRACKING -> RELOC -> TRACKING), the backend hook order, and that frame groups (batched, speculative network
+calls) leave every pose bit-identical to one-frame-at-a-time processing."""
+import numpy as np
+import pytest
+import torch
+
+from mast3r_slam import synthetic
+
+pytestmark = pytest.mark.gpu
+
+H, W = 96, 128
+
+
+class RoomModel:
+    """Surface of Mast3rHIP (_encode_image, decode_pair), batch capable; counts its calls and rows."""
+
+    def __init__(self, device, noise=0.001):
+        self.device, self.noise = device, noise
+        self.enc_calls, self.dec_calls, self.dec_rows = 0, 0, 0
+
+    def _encode_image(self, img, true_shape=None):
+        self.enc_calls += 1
+        B = img.shape[0]
+        n = (H // 16) * (W // 16)
+        k = torch.round(img.reshape(B, -1)[:, 0] * 1000.0)
+        feat = k.reshape(B, 1, 1).expand(B, n, 8).contiguous().float()
+        return feat, torch.zeros((B, n, 2), dtype=torch.long, device=self.device), None
+
+    def decode_pair(self, feat1, feat2, h, w):
+        self.dec_calls += 1
+        self.dec_rows += feat1.shape[0]
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        outs = ([], [])
+        for b in range(feat1.shape[0]):
+            pr = synthetic.make_pair(int(feat1[b, 0, 0]), int(feat2[b, 0, 0]), h=h, w=w, seed=1, noise=self.noise)
+            outs[0].append((pr["X11"], pr["C11"], pr["D11"], pr["Q11"]))
+            outs[1].append((pr["X21"], pr["C21"], pr["D21"], pr["Q21"]))
+        res = []
+        for side in outs:
+            X, C, D, Q = (np.stack(v) for v in zip(*side))
+            res.append(dict(pts3d=t(X), conf=t(C), desc=t(D), desc_conf=t(Q)))
+        return res[0], res[1]
+
+
+def _frames(ks, device):
+    from mast3r_slam.frame import Frame
+
+    return [Frame(i, torch.full((1, 3, H, W), k / 1000.0, device=device), torch.tensor([[H, W]]), torch.tensor([[H, W]]), None)
+            for i, k in enumerate(ks)]
+
+
+def _run(device, ks, frame_group, tsdf=False):
+    from mast3r_slam.config import config
+    from mast3r_slam.slam_system import SlamSystem
+
+    model = RoomModel(device)
+    tcfg = dict(config["tsdf_global"], enabled=True, pre_icp_iters=0, max_iterations=0, hash_capacity=1 << 18) if tsdf else None
+    torch.manual_seed(0)
+    system = SlamSystem(model, device, frame_group=frame_group, tsdf_global_cfg=tcfg)
+    frames = _frames(ks, device)
+    res = system.run(frames)
+    system.shutdown()
+    torch.cuda.synchronize()
+    return system, model, frames, res
+
+
+@pytest.fixture
+def eager_keyframes(monkeypatch):
+    """The room views overlap a lot (a new keyframe at the reference's 0.333 needs a gap of ~110 trajectory steps):
+    raise the threshold so that a gap of ~21 steps (7 frames at stride 3) already gives one."""
+    from mast3r_slam.config import config
+
+    monkeypatch.setitem(config["tracking"], "match_frac_thresh", 0.72)
+
+
+def _gauge(T0, Tk):
+    return synthetic.sim3_act(synthetic.sim3_inv(T0), Tk[:3][None])[0]
+
+
+def test_trajectory_and_backend(device, eager_keyframes):
+    from mast3r_slam.frame import Mode
+
+    ks = list(range(0, 60, 3))
+    system, model, frames, res = _run(device, ks, 1, tsdf=True)
+    assert res[0]["mode"] == Mode.INIT and all(r["mode"] == Mode.TRACKING for r in res[1:])
+    n_kf = len(system.keyframes)
+    assert n_kf >= 3 and system.stats["keyframes"] == n_kf             # the view changes enough for new keyframes
+    assert system.factor_graph.ii.numel() == n_kf - 1                    # one consecutive edge per new keyframe
+    T0 = synthetic.camera_pose(ks[0])
+    errs = [np.linalg.norm(f.T_WC.data.reshape(-1)[:3].cpu().numpy() - _gauge(T0, synthetic.camera_pose(k)))
+            for f, k in zip(frames[1:], ks[1:])]
+    assert max(errs) < 0.05, errs
+    assert system.tsdf_manager.integrator.next_idx == n_kf               # every keyframe was fused
+    assert system.tsdf_manager.volume.stats()["valid_voxels"] > 1000
+
+
+@pytest.mark.parametrize("group", [2, 4])
+def test_frame_groups_are_bit_identical(device, group, eager_keyframes):
+    ks = list(range(0, 60, 3))
+    s1, m1, f1, r1 = _run(device, ks, 1)
+    sg, mg, fg, rg = _run(device, ks, group)
+    assert [r["new_kf"] for r in r1] == [r["new_kf"] for r in rg]
+    for a, b in zip(f1, fg):
+        assert torch.equal(a.T_WC.data, b.T_WC.data)
+        assert torch.equal(a.X_canon, b.X_canon) and torch.equal(a.C, b.C)
+    for i in range(len(s1.keyframes)):
+        assert torch.equal(s1.keyframes[i].T_WC.data, sg.keyframes[i].T_WC.data)
+    # fewer, larger network calls; rows decoded in vain only behind keyframe changes
+    assert mg.enc_calls <= (len(ks) + group - 1) // group + 1 and m1.enc_calls == len(ks)
+    assert mg.dec_calls < m1.dec_calls
+    n_kf = len(sg.keyframes)
+    assert sg.stats["void_rows"] <= (group - 1) * n_kf
+    assert sg.stats["decoded_rows"] == len(ks) - 1 + sg.stats["void_rows"]
+
+
+def test_relocalisation(device):
+    """A frame from the other side of the room cannot be tracked (RELOC); the next frame near the map is
+    initialised mono, matched against the most recent keyframe and re-enters the graph (main.py:28-71)."""
+    from mast3r_slam.frame import Mode
+
+    ks = [0, 3, 6, 9, 250, 12, 15, 18]
+    system, model, frames, res = _run(device, ks, 2)
+    assert res[4]["try_reloc"] and res[5]["mode"] == Mode.RELOC
+    assert system.stats["relocalised"] == 1 and res[6]["mode"] == Mode.TRACKING
+    T0 = synthetic.camera_pose(0)
+    for f, k in zip(frames[6:], ks[6:]):
+        err = np.linalg.norm(f.T_WC.data.reshape(-1)[:3].cpu().numpy() - _gauge(T0, synthetic.camera_pose(k)))
+        assert err < 0.05, (k, err)

@@ -13,6 +13,10 @@ SHAPES = [  # (M, N, K): encoder / decoder / head linears at B=1 and at the 4-ed
     (3072, 2304, 768), (3072, 768, 768), (3072, 1536, 768), (3072, 3072, 768), (3072, 768, 3072), (3072, 768, 1024),
     (3072, 7168, 1792), (3072, 6400, 7168), (8192, 8192, 8192),
 ]
+if os.environ.get("MSLAM_TUNE_SET") == "groups":   # frame groups of 2 / 4 and the batch-8 backend call
+    SHAPES = [(M, N, K) for M in (1536, 3072, 6144) for N, K in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096))]
+    SHAPES += [(M, N, K) for M in (1536, 6144)
+               for N, K in ((2304, 768), (768, 768), (1536, 768), (3072, 768), (768, 3072), (768, 1024))]
 if __name__ == "__main__":
     cfg = os.environ.get("MSLAM_GEMM", "auto")
     for M, N, K in SHAPES:

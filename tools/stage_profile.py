@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs ONE network stage repeatedly (for rocprofv3 --kernel-trace --stats): stage_profile.py enc|dec1|dec4 [n]"""
+"""Runs ONE network stage repeatedly (for rocprofv3 --kernel-trace --stats): stage_profile.py enc|enc4|dec1|dec4 [n]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mast3r-slam-quality-dualtsdf_amd")]
@@ -15,9 +15,12 @@ img = torch.rand(1, 3, H, W, device=dev) * 2 - 1
 feat = model._encode_image(img)[0]
 B = 4 if stage == "dec4" else 1
 fb = feat.expand(B, -1, -1).contiguous()
+img4 = img.expand(4, -1, -1, -1).contiguous()
 for _ in range(n):
     if stage == "enc":
         model._encode_image(img)
+    elif stage == "enc4":
+        model._encode_image(img4)
     else:
         model.decode_pair(fb, fb, H, W)
 torch.cuda.synchronize()
