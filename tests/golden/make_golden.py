@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block  evaluate
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -814,6 +814,114 @@ def section_refine_block():
     np.savez_compressed(os.path.join(HERE, "refine_block.npz"), **out, **meta())
 
 
+def section_evaluate():
+    """evaluate.py:23-106 (save_traj, save_reconstruction -> save_ply) of the reference module on three synthetic
+    keyframes.  cv2 / dataloader / frame are stubbed (unused by these functions), lietorch is a data holder so that the
+    reference's own lietorch_utils.as_SE3 runs, and plyfile is a stub that captures the structured vertex array the
+    reference hands to PlyElement.describe (file bytes of plyfile itself: unpinned)."""
+    import tempfile
+    import types
+
+    from mast3r_slam import synthetic
+
+    names = ("lietorch", "cv2", "plyfile", "mast3r_slam", "mast3r_slam.config", "mast3r_slam.dataloader", "mast3r_slam.frame",
+             "mast3r_slam.lietorch_utils", "mast3r_slam.geometry")
+    saved = {k: sys.modules.get(k) for k in names}
+    captured = {}
+    try:
+        class _G:
+            def __init__(self, data):
+                self.data = data
+
+        sys.modules["lietorch"] = types.SimpleNamespace(SE3=type("SE3", (_G,), {}), Sim3=type("Sim3", (_G,), {}))
+        sys.modules["cv2"] = types.SimpleNamespace()
+
+        class _PlyElement:
+            @staticmethod
+            def describe(arr, name):
+                captured["pcd"], captured["name"] = arr.copy(), name
+                return arr
+
+        class _PlyData:
+            def __init__(self, elements, text=True):
+                captured["text"] = text
+
+            def write(self, filename):
+                captured["filename"] = str(filename)
+
+        sys.modules["plyfile"] = types.SimpleNamespace(PlyData=_PlyData, PlyElement=_PlyElement)
+        ref_config = load_by_path("ref_config_ev", f"{REF}/mast3r_slam/config.py")
+        cwd = os.getcwd()
+        os.chdir(REF)
+        try:
+            ref_config.load_config("config/base.yaml")
+        finally:
+            os.chdir(cwd)
+        pkg = types.ModuleType("mast3r_slam")
+        pkg.__path__ = []
+        sys.modules["mast3r_slam"] = pkg
+        sys.modules["mast3r_slam.config"] = ref_config
+        sys.modules["mast3r_slam.dataloader"] = types.SimpleNamespace(Intrinsics=None)
+        sys.modules["mast3r_slam.frame"] = types.SimpleNamespace(SharedKeyframes=None)
+        sys.modules["mast3r_slam.lietorch_utils"] = load_by_path("ref_lietorch_utils_ev", f"{REF}/mast3r_slam/lietorch_utils.py")
+        sys.modules["mast3r_slam.geometry"] = types.SimpleNamespace(constrain_points_to_ray=None)
+        ev = load_by_path("ref_evaluate", f"{REF}/mast3r_slam/evaluate.py")
+
+        H, W = 24, 32
+        rng = np.random.default_rng(8)
+
+        class Pose:
+            def __init__(self, T):
+                self.T = T
+                self.data = torch.from_numpy(T.astype(np.float32)).reshape(1, 8)
+
+            def act(self, X):
+                return torch.from_numpy(synthetic.sim3_act(self.T, X.numpy().astype(np.float64)).astype(np.float32))
+
+        class KF:
+            pass
+
+        kfs, out = [], {}
+        for i, k in enumerate((0, 9, 21)):
+            T = synthetic.camera_pose(k)
+            T[7] = 1.0 + 0.05 * i
+            kf = KF()
+            kf.frame_id = 3 * i + 1
+            kf.T_WC = Pose(T)
+            kf.X_canon = torch.from_numpy(synthetic.render_pointmap(synthetic.camera_pose(k), H, W).reshape(-1, 3).astype(np.float32))
+            kf.uimg = torch.from_numpy(rng.uniform(0, 1, (H, W, 3)).astype(np.float32))
+            C = torch.from_numpy(rng.uniform(0.5, 3.0, (H * W, 1)).astype(np.float32))
+            kf.get_average_conf = (lambda c: (lambda: c))(C)
+            kf.img_shape = torch.tensor([[H, W]])
+            kf.K = None
+            kfs.append(kf)
+            out[f"T_{i}"], out[f"X_{i}"], out[f"uimg_{i}"], out[f"C_{i}"] = T.astype(np.float32), kf.X_canon.numpy(), kf.uimg.numpy(), C.numpy()
+            out[f"Xw_{i}"] = kf.T_WC.act(kf.X_canon).numpy()
+        timestamps = [1305031102.175304 + 0.0333 * j for j in range(8)]
+        with tempfile.TemporaryDirectory() as d:
+            ev.save_traj(d, "traj.txt", timestamps, kfs)
+            out["traj_txt"] = np.array(open(os.path.join(d, "traj.txt")).read())
+            ev.save_reconstruction(d, "rec.ply", kfs, 1.5)
+        out["timestamps"] = np.array(timestamps)
+        out["frame_ids"] = np.array([kf.frame_id for kf in kfs])
+        pcd = captured["pcd"]
+        out["ply_names"] = np.array(list(pcd.dtype.names))
+        out["ply_types"] = np.array([pcd.dtype[n].str for n in pcd.dtype.names])
+        for n in pcd.dtype.names:
+            out["ply_" + n] = pcd[n]
+        out["ply_text"] = np.array(captured["text"])
+        out["c_conf_threshold"] = np.array(1.5)
+        np.savez_compressed(os.path.join(HERE, "evaluate.npz"), **out, **meta())
+        print("evaluate.npz:", str(out["traj_txt"]).splitlines()[0], "| ply vertices", len(pcd), captured["name"], captured["text"])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+SECTIONS["evaluate"] = section_evaluate
 SECTIONS["refine_block"] = section_refine_block
 SECTIONS["utils_wrappers"] = section_utils_wrappers
 SECTIONS["track_logic"] = section_track_logic
