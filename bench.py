@@ -370,12 +370,16 @@ class Pipeline:
         return groups * B * self.flop_scale * GF_TRACK + a.edges_per_kf * GF_EDGE, ms
 
     def dominant_kernel_probe(self, iters=50):
-        """The kernel with the largest share of the step (profiles/r01_bench_kernel_stats.csv): the 64x64-tile
-        bf16 GEMM at the tracked frame's row count, here on the encoder's fc1 shape (768 x 4096 x 1024, GELU),
-        launched through the C ABI and event-timed on its stream."""
+        """The kernel with the largest share of the step (profiles/r01_bench_kernel_stats.csv): the bf16 GEMM on the
+        encoder's fc1 shape at the frame group's row count (768 B x 4096 x 1024, GELU) - the 256x256-tile, 16-wave
+        instantiation from B = 3 up, the 64x64-tile one at B = 1 - launched through the C ABI, event-timed on its stream."""
         import mslam_hip as m
 
-        M, N, K = 768, 4096, 1024
+        M, N, K = 768 * self.B, 4096, 1024
+        tiles256 = ((M + 255) // 256) * ((N + 255) // 256)
+        name = ("gemm_bf16_kernel<4,4,2,2,2,false> (256x256 tile, 16 waves, LDS-DMA ring 2)" if tiles256 >= 128 else
+                "gemm_bf16_kernel<2,4,2,1,2,false> (128x128 tile, 8 waves, LDS-DMA ring 2)" if tiles256 * 4 >= 300 else
+                "gemm_bf16_kernel<2,2,1,1,2,false> (64x64 tile, LDS-DMA ring 2)")
         A = torch.randn(M, K, device=self.dev).to(torch.bfloat16)
         Wt = (torch.randn(N, K, device=self.dev) / K ** 0.5).to(torch.bfloat16)
         bias = torch.randn(N, device=self.dev)
@@ -392,7 +396,7 @@ class Pipeline:
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / iters
-        return {"name": "gemm_bf16_kernel<2,2,1,1,2,false> (64x64 tile, LDS-DMA ring 2)", "shape": [M, N, K],
+        return {"name": name, "shape": [M, N, K],
                 "gflop_per_launch": 2e-9 * M * N * K, "us_per_launch": us, "tflops": 2e-6 * M * N * K / us}
 
     def gflop_per_step_avg(self):

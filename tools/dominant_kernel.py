@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Launches only the kernel bench.py names as dominant (64x64-tile bf16 GEMM, 768 x 4096 x 1024, GELU epilogue) so
+"""Launches only the kernel bench.py names as dominant (bf16 GEMM on the encoder's fc1 shape at the frame group's row
+count: 256x256-tile instantiation at 3072 x 4096 x 1024 for the default group of 4; `dominant_kernel.py 1` gives the
+64x64-tile one at 768 rows), GELU epilogue, so
 that `rocprofv3 --kernel-trace --stats -- python3 tools/dominant_kernel.py` gives its average duration in isolation
 (profiles/r01_dominant_kernel_stats.csv) next to the event-timed figure bench.py prints."""
 import os, sys
@@ -9,7 +11,7 @@ import torch
 import mslam_hip as m
 
 dev = torch.device("cuda:0")
-M, N, K = 768, 4096, 1024
+M, N, K = 768 * (int(sys.argv[1]) if len(sys.argv) > 1 else 4), 4096, 1024
 A = torch.randn(M, K, device=dev).to(torch.bfloat16)
 W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
 bias = torch.randn(N, device=dev)
