@@ -557,7 +557,8 @@ def main():
                          "frac": achieved / PEAK_BF16_TFLOPS,
                          # fabric-side bytes of ONE tracked frame's network pass (encode + decode), rocprofv3 --pmc
                          # FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE in separate passes: profiles/r01_pmc_hbm_traffic.json
-                         "traffic": 10.79e9, "traffic_unit": "bytes per tracked-frame network pass (1.514 TFLOP)",
+                         # (measured for groups of 1 and of 4 frames; null for other group sizes)
+                         "traffic": {1: 10.79e9, 4: 8.148e9}.get(pipe.B), "traffic_unit": "bytes per tracked-frame network pass (1.514 TFLOP)",
                          "dominant_kernel": dom,
                          "kernel": "gemm_bf16_kernel + attention_kernel (MASt3R forward: algorithmic GFLOP / event-timed "
                                    "stage ms, stages run back to back without the frontend overlap)",
