@@ -3,8 +3,13 @@
 main.py runs the tracking frontend (main.py:325-446) and the backend (run_backend, main.py:73-163; relocalization,
 main.py:28-71) as two processes that share keyframes through CUDA-IPC buffers, manager locks and 10 ms polling.
 `SlamSystem` is the same state machine (Mode.INIT / TRACKING / RELOC, the same calls in the same order) in one
-process with the semantics of the reference's `single_thread: True` evaluation configs (the backend task of a
-keyframe is finished before the next frame is tracked, main.py:391-395), plus two things the split made impossible:
+process.  `backend="inline"` (default) has the semantics of the reference's `single_thread: True` evaluation configs
+(the backend task of a keyframe is finished before the next frame is tracked, main.py:391-395) and is deterministic;
+`backend="thread"` runs the backend on its own host thread and HIP stream beside the tracking loop, as the reference's
+second process does: the symmetric edge inference (most of a backend task) overlaps tracking, while everything that
+reads or writes keyframe pointmaps / poses (the tracking step on one side; global GN + TSDF hook on the other) runs in
+critical sections that hand the data over between the two streams with events instead of locks + polling + IPC copies.
+Two more things the split made impossible:
 
 * **frame groups** (`frame_group` = B > 1): the encoder runs B frames ahead on its own stream and the two-view
   forward of the next B frames against the current keyframe is ONE batch call
@@ -17,6 +22,10 @@ keyframe is finished before the next frame is tracked, main.py:391-395), plus tw
 Retrieval (retrieval_database.py, ASMK) is not available offline; `retriever` is any object with the reference's
 `update(frame, add_after_query, k, min_thresh) -> [keyframe ids]`.  The default stand-in proposes no loop-closure edges
 and offers the most recent keyframes as relocalisation candidates."""
+import contextlib
+import queue
+import threading
+
 import torch
 
 from lietorch_hip import Sim3
@@ -41,8 +50,41 @@ class RecentKeyframes:
         return list(range(max(0, n - self.k), n))[::-1]
 
 
+class _BackendThread(threading.Thread):
+    """run_backend (main.py:73-163) as a host thread with its own stream; tasks are keyframe indices."""
+
+    def __init__(self, system):
+        super().__init__(daemon=True)
+        self.system, self.q, self.error = system, queue.Queue(), None
+        self.start()
+
+    def run(self):
+        dev = self.system.device
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            while True:
+                task = self.q.get()
+                try:
+                    if task is None:
+                        return
+                    if self.error is None:
+                        idx, ev = task
+                        torch.cuda.current_stream(dev).wait_event(ev)   # the keyframe was produced on the tracking stream
+                        self.system._backend(idx)
+                except Exception as e:   # surfaced by drain()
+                    self.error = e
+                finally:
+                    self.q.task_done()
+
+    def drain(self):
+        self.q.join()
+        if self.error is not None:
+            raise self.error
+
+
 class SlamSystem:
-    def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None):
+    def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
+                 backend="inline"):
         self.model, self.device, self.K = model, torch.device(device), K
         self.keyframes = KeyframeStore() if keyframes is None else keyframes
         self.tracker = FrameTracker(model, self.keyframes, device)
@@ -54,6 +96,10 @@ class SlamSystem:
 
             self.tsdf_manager = TSDFGlobalManager(self.keyframes, tsdf_global_cfg, config.get("use_calib", False), device)
             self.tsdf_manager.start()
+        assert backend in ("inline", "thread")
+        self._lock = threading.RLock()
+        self._hand = {"main": None, "backend": None}   # event at the end of each side's last critical section
+        self._worker = _BackendThread(self) if backend == "thread" else None
         self.mode = Mode.INIT
         self.last_T = None
         self.frame_group = max(1, int(frame_group))
@@ -79,38 +125,75 @@ class SlamSystem:
         self.stats["frames"] += 1
         add_new_kf = try_reloc = False
         mode = self.mode
-        if mode == Mode.INIT:                           # main.py:359-367
-            X_init, C_init = mu.mast3r_inference_mono(self.model, frame)
-            frame.update_pointmap(X_init, C_init)
-            self.keyframes.append(frame)
-            self.stats["keyframes"] += 1
-            self.mode = Mode.TRACKING
-            self.last_T = frame.T_WC
-            self._backend(len(self.keyframes) - 1)
-            return dict(mode=mode, new_kf=True, try_reloc=False)
-        if mode == Mode.TRACKING:                       # main.py:369-373
-            add_new_kf, _, try_reloc = self.tracker.track(frame)
-            if try_reloc:
-                self.mode = Mode.RELOC
-            self.last_T = frame.T_WC
-        elif mode == Mode.RELOC:                        # main.py:375-385
-            X, C = mu.mast3r_inference_mono(self.model, frame)
-            frame.update_pointmap(X, C)
-            self.last_T = frame.T_WC
-            if self._relocalization(frame):
+        if mode == Mode.RELOC and self._worker is not None:
+            self._worker.drain()                        # relocalisation edits the factor graph: the backend must be idle
+        with self._critical("main"):
+            if mode == Mode.INIT:                       # main.py:359-367
+                X_init, C_init = mu.mast3r_inference_mono(self.model, frame)
+                frame.update_pointmap(X_init, C_init)
+                add_new_kf = True
                 self.mode = Mode.TRACKING
-                self.stats["relocalised"] += 1
-        else:
-            raise Exception("Invalid mode")
-        if add_new_kf:                                  # main.py:387-395
-            self.keyframes.append(frame)
-            self.stats["keyframes"] += 1
-            self._backend(len(self.keyframes) - 1)
+            elif mode == Mode.TRACKING:                 # main.py:369-373
+                add_new_kf, _, try_reloc = self.tracker.track(frame)
+                if try_reloc:
+                    self.mode = Mode.RELOC
+            elif mode == Mode.RELOC:                    # main.py:375-385
+                X, C = mu.mast3r_inference_mono(self.model, frame)
+                frame.update_pointmap(X, C)
+                if self._relocalization(frame):
+                    self.mode = Mode.TRACKING
+                    self.stats["relocalised"] += 1
+            else:
+                raise Exception("Invalid mode")
+            self.last_T = frame.T_WC
+            if add_new_kf:                              # main.py:387-395
+                self.keyframes.append(frame)
+                self.stats["keyframes"] += 1
+        if add_new_kf:
+            self._queue_backend(len(self.keyframes) - 1)
         return dict(mode=mode, new_kf=bool(add_new_kf), try_reloc=bool(try_reloc))
 
+    def drain(self):
+        """Wait until every queued backend task has been issued (backend="thread")."""
+        if self._worker is not None:
+            self._worker.drain()
+
     def shutdown(self):
+        if self._worker is not None:
+            self._worker.drain()
+            self._worker.q.put(None)
+            self._worker.join(timeout=5.0)
+            self._worker = None
         if self.tsdf_manager is not None:
             self.tsdf_manager.shutdown()
+
+    @contextlib.contextmanager
+    def _critical(self, me):
+        """Section that reads or writes keyframe pointmaps / poses.  Inline backend: nothing to do.  Threaded backend:
+        one side at a time (host lock), and the entering side's stream first waits for the event the other side
+        recorded when it left its last section, so data written on one stream is visible to the other."""
+        if self._worker is None:
+            yield
+            return
+        other = "backend" if me == "main" else "main"
+        with self._lock:
+            stream = torch.cuda.current_stream(self.device)
+            if self._hand[other] is not None:
+                stream.wait_event(self._hand[other])
+            try:
+                yield
+            finally:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                self._hand[me] = ev
+
+    def _queue_backend(self, idx):
+        if self._worker is None:
+            self._backend(idx)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._worker.q.put((idx, ev))
 
     # ------------------------------------------------------------------ frame groups
     def _wait_encoded(self, frame):
@@ -165,11 +248,12 @@ class SlamSystem:
         kf_idx.discard(idx)
         kf_idx = list(kf_idx)
         frame_idx = [idx] * len(kf_idx)
-        if kf_idx:
+        if kf_idx:   # symmetric edge inference + matching: reads only the keyframes' (immutable) features
             self.factor_graph.add_factors(kf_idx, frame_idx, config["local_opt"]["min_match_frac"])
-        self._solve()
-        if self.tsdf_manager is not None:
-            self.tsdf_manager.on_after_backend_solve(self.factor_graph)
+        with self._critical("backend"):
+            self._solve()
+            if self.tsdf_manager is not None:
+                self.tsdf_manager.on_after_backend_solve(self.factor_graph)
 
     def _solve(self):
         if config["use_calib"]:

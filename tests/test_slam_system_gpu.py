@@ -51,17 +51,17 @@ def _frames(ks, device):
             for i, k in enumerate(ks)]
 
 
-def _run(device, ks, frame_group, tsdf=False):
+def _run(device, ks, frame_group, tsdf=False, backend="inline"):
     from mast3r_slam.config import config
     from mast3r_slam.slam_system import SlamSystem
 
     model = RoomModel(device)
     tcfg = dict(config["tsdf_global"], enabled=True, pre_icp_iters=0, max_iterations=0, hash_capacity=1 << 18) if tsdf else None
     torch.manual_seed(0)
-    system = SlamSystem(model, device, frame_group=frame_group, tsdf_global_cfg=tcfg)
+    system = SlamSystem(model, device, frame_group=frame_group, tsdf_global_cfg=tcfg, backend=backend)
     frames = _frames(ks, device)
     res = system.run(frames)
-    system.shutdown()
+    system.shutdown()                                   # drains the backend thread, if any
     torch.cuda.synchronize()
     return system, model, frames, res
 
@@ -94,6 +94,24 @@ def test_trajectory_and_backend(device, eager_keyframes):
     assert max(errs) < 0.05, errs
     assert system.tsdf_manager.integrator.next_idx == n_kf               # every keyframe was fused
     assert system.tsdf_manager.volume.stats()["valid_voxels"] > 1000
+
+
+def test_threaded_backend(device, eager_keyframes):
+    """backend="thread": the keyframe tasks run on their own host thread + stream beside tracking (event hand-over of the
+    keyframe data between the two streams); interleaving is timing dependent, so the check is on the outcome."""
+    ks = list(range(0, 60, 3))
+    system, model, frames, res = _run(device, ks, 2, tsdf=True, backend="thread")
+    n_kf = len(system.keyframes)
+    assert n_kf >= 3 and system.factor_graph.ii.numel() == n_kf - 1
+    assert system.tsdf_manager.integrator.next_idx == n_kf
+    T0 = synthetic.camera_pose(ks[0])
+    errs = [np.linalg.norm(f.T_WC.data.reshape(-1)[:3].cpu().numpy() - _gauge(T0, synthetic.camera_pose(k)))
+            for f, k in zip(frames[1:], ks[1:])]
+    assert max(errs) < 0.05, errs
+    for i in range(1, n_kf):
+        kf = system.keyframes[i]
+        err = np.linalg.norm(kf.T_WC.data.reshape(-1)[:3].cpu().numpy() - _gauge(T0, synthetic.camera_pose(ks[kf.frame_id])))
+        assert err < 0.05, (i, err)
 
 
 @pytest.mark.parametrize("group", [2, 4])
