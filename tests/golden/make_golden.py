@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block  evaluate
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block  evaluate  dataloader
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -921,6 +921,88 @@ def section_evaluate():
                 sys.modules[k] = v
 
 
+sys.path.insert(0, HERE)
+from dataset_tree import build_dataset_tree  # noqa: E402  (tests/golden/dataset_tree.py, shared with tests/test_dataloader.py)
+
+
+def section_dataloader():
+    """The file-based readers of dataloader.py (TUM, 7-Scenes, RGBFiles, ETH3D, Replica; use_calib False) and load_dataset
+    on a small directory tree.  cv2.imread / cvtColor are a PIL shim (same decoded bytes for PNG), natsort.natsorted is a
+    digit-aware sort written here (natsort itself: unpinned), pyrealsense2 an empty stub, resize_img the mirror's (pinned
+    separately by resize_img.npz)."""
+    import tempfile
+    import types
+
+    import PIL.Image
+    from mast3r_slam.mast3r_utils import resize_img as my_resize_img
+
+    names = ("cv2", "natsort", "pyrealsense2", "mast3r_slam", "mast3r_slam.config", "mast3r_slam.mast3r_utils")
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        def imread(path, flag=1):
+            im = PIL.Image.open(path)
+            return np.asarray(im.convert("L")) if flag == 0 else np.asarray(im.convert("RGB"))[..., ::-1].copy()
+
+        def cvtColor(img, code):
+            return img[..., ::-1].copy() if code == "BGR2RGB" else np.stack([img] * 3, -1)
+
+        sys.modules["cv2"] = types.SimpleNamespace(imread=imread, cvtColor=cvtColor, COLOR_BGR2RGB="BGR2RGB",
+                                                   COLOR_GRAY2BGR="GRAY2BGR", IMREAD_GRAYSCALE=0)
+        nkey = lambda p: [int(t) if t.isdigit() else t.lower() for t in __import__("re").split(r"(\d+)", str(p))]
+        sys.modules["natsort"] = types.SimpleNamespace(natsorted=lambda seq: sorted(seq, key=nkey))
+        sys.modules["pyrealsense2"] = types.SimpleNamespace()
+        ref_config = load_by_path("ref_config_dl", f"{REF}/mast3r_slam/config.py")
+        cwd = os.getcwd()
+        os.chdir(REF)
+        try:
+            ref_config.load_config("config/base.yaml")
+        finally:
+            os.chdir(cwd)
+        pkg = types.ModuleType("mast3r_slam")
+        pkg.__path__ = []
+        sys.modules["mast3r_slam"] = pkg
+        sys.modules["mast3r_slam.config"] = ref_config
+        sys.modules["mast3r_slam.mast3r_utils"] = types.SimpleNamespace(resize_img=my_resize_img)
+        if not hasattr(np, "unicode_"):
+            np.unicode_ = np.str_          # the reference predates NumPy 2
+        dl = load_by_path("ref_dataloader", f"{REF}/mast3r_slam/dataloader.py")
+        rng = np.random.default_rng(12)
+        imgs = rng.integers(0, 256, (5, 48, 64, 3), dtype=np.uint8)
+        out = dict(imgs=imgs)
+        with tempfile.TemporaryDirectory() as root:
+            layout = build_dataset_tree(root, imgs)
+            for cls, rel in layout.items():
+                ds = dl.load_dataset(os.path.join(root, rel))
+                assert type(ds).__name__ == cls, (type(ds).__name__, cls)
+                out[f"{cls}_len"] = np.array(len(ds))
+                out[f"{cls}_timestamps"] = np.array([str(t) for t in ds.timestamps])
+                out[f"{cls}_files"] = np.array([os.path.relpath(str(f), root) for f in ds.rgb_files])
+                t0, im0 = ds[0]
+                t1, im1 = ds[len(ds) - 1]
+                out[f"{cls}_t0"], out[f"{cls}_img0"], out[f"{cls}_imgN"] = np.array(str(t0)), im0, im1
+                shp, raw = ds.get_img_shape()
+                out[f"{cls}_shape"] = np.array([*shp, *raw])
+                out[f"{cls}_flags"] = np.array([ds.has_calib(), ds.use_calibration, ds.save_results])
+                ds.subsample(2)
+                out[f"{cls}_sub_files"] = np.array([os.path.relpath(str(f), root) for f in ds.rgb_files])
+                print(cls, len(out[f"{cls}_files"]), list(out[f"{cls}_timestamps"][:2]), out[f"{cls}_shape"].tolist(), out[f"{cls}_flags"].tolist())
+        out["layout"] = np.array(json_dumps(layout))
+        np.savez_compressed(os.path.join(HERE, "dataloader.npz"), **out, **meta())
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def json_dumps(o):
+    import json
+
+    return json.dumps(o, sort_keys=True)
+
+
+SECTIONS["dataloader"] = section_dataloader
 SECTIONS["evaluate"] = section_evaluate
 SECTIONS["refine_block"] = section_refine_block
 SECTIONS["utils_wrappers"] = section_utils_wrappers
