@@ -10,6 +10,8 @@ import threading
 from enum import Enum
 from typing import Optional
 
+import copy
+
 import torch
 
 from lietorch_hip import Sim3
@@ -126,7 +128,9 @@ class KeyframeStore:
         self._kfs[int(idx)] = frame
 
     def append(self, frame):
-        self._kfs.append(frame)
+        """Copy-in, as SharedKeyframes does (frame.py:312-314): later updates of the keyframe (pointmap fusion, backend
+        poses) do not reach back into the caller's Frame object.  Tensors are shared, not cloned."""
+        self._kfs.append(copy.copy(frame))
 
     def pop_last(self):
         self._kfs.pop()

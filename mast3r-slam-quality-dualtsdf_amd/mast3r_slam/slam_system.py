@@ -118,7 +118,8 @@ class SlamSystem:
         return out
 
     def step(self, frame):
-        """One iteration of the main loop for an already created frame -> dict(mode, new_kf, try_reloc)."""
+        """One iteration of the main loop for an already created frame -> dict(mode, new_kf, try_reloc, pose) with
+        `pose` = the frame's T_WC data as tracked (before any later backend update of a keyframe copy)."""
         self._wait_encoded(frame)
         if self.last_T is not None:                     # "last camera pose for the frame" (main.py:351-356)
             frame.T_WC = Sim3(self.last_T.data.clone())
@@ -151,7 +152,7 @@ class SlamSystem:
                 self.stats["keyframes"] += 1
         if add_new_kf:
             self._queue_backend(len(self.keyframes) - 1)
-        return dict(mode=mode, new_kf=bool(add_new_kf), try_reloc=bool(try_reloc))
+        return dict(mode=mode, new_kf=bool(add_new_kf), try_reloc=bool(try_reloc), pose=frame.T_WC.data.clone())
 
     def drain(self):
         """Wait until every queued backend task has been issued (backend="thread")."""

@@ -25,7 +25,7 @@ class RoomModel:
         B = img.shape[0]
         n = (H // 16) * (W // 16)
         k = torch.round(img.reshape(B, -1)[:, 0] * 1000.0)
-        feat = k.reshape(B, 1, 1).expand(B, n, 8).contiguous().float()
+        feat = k.reshape(B, 1, 1).expand(B, n, 1024).contiguous().float()
         return feat, torch.zeros((B, n, 2), dtype=torch.long, device=self.device), None
 
     def decode_pair(self, feat1, feat2, h, w):
@@ -47,18 +47,23 @@ class RoomModel:
 def _frames(ks, device):
     from mast3r_slam.frame import Frame
 
-    return [Frame(i, torch.full((1, 3, H, W), k / 1000.0, device=device), torch.tensor([[H, W]]), torch.tensor([[H, W]]), None)
-            for i, k in enumerate(ks)]
+    return [Frame(i, torch.full((1, 3, H, W), k / 1000.0, device=device), torch.tensor([[H, W]]), torch.tensor([[H, W]]),
+                  torch.zeros(H, W, 3)) for i, k in enumerate(ks)]
 
 
-def _run(device, ks, frame_group, tsdf=False, backend="inline"):
+def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=False):
     from mast3r_slam.config import config
     from mast3r_slam.slam_system import SlamSystem
 
     model = RoomModel(device)
     tcfg = dict(config["tsdf_global"], enabled=True, pre_icp_iters=0, max_iterations=0, hash_capacity=1 << 18) if tsdf else None
     torch.manual_seed(0)
-    system = SlamSystem(model, device, frame_group=frame_group, tsdf_global_cfg=tcfg, backend=backend)
+    store = None
+    if shared_store:   # the reference's slot-buffer layout (frame.py:220-334) instead of the unbounded list
+        from mast3r_slam.frame import SharedKeyframes
+
+        store = SharedKeyframes(None, H, W, buffer=16, device=device)
+    system = SlamSystem(model, device, frame_group=frame_group, tsdf_global_cfg=tcfg, backend=backend, keyframes=store)
     frames = _frames(ks, device)
     res = system.run(frames)
     system.shutdown()                                   # drains the backend thread, if any
@@ -131,6 +136,22 @@ def test_frame_groups_are_bit_identical(device, group, eager_keyframes):
     n_kf = len(sg.keyframes)
     assert sg.stats["void_rows"] <= (group - 1) * n_kf
     assert sg.stats["decoded_rows"] == len(ks) - 1 + sg.stats["void_rows"]
+
+
+def test_shared_keyframe_buffers_give_the_same_trajectory(device, eager_keyframes):
+    """SlamSystem on the SharedKeyframes slot buffers (the reference's data layout contract) and on the
+    plain list store: identical poses, keyframes and graph."""
+    ks = list(range(0, 60, 3))
+    sl, _, fl, rl = _run(device, ks, 2)
+    ss, _, fs, rs = _run(device, ks, 2, shared_store=True)
+    assert len(sl.keyframes) == len(ss.keyframes) >= 3
+    for a, b, ra, rb in zip(fl, fs, rl, rs):
+        assert torch.equal(ra["pose"], rb["pose"]) and torch.equal(a.T_WC.data, b.T_WC.data)
+    for i in range(len(sl.keyframes)):
+        ka, kb = sl.keyframes[i], ss.keyframes[i]
+        assert ka.frame_id == kb.frame_id and torch.equal(ka.T_WC.data, kb.T_WC.data)
+        assert torch.equal(ka.X_canon, kb.X_canon) and torch.equal(ka.C, kb.C) and ka.N == kb.N
+    assert torch.equal(sl.factor_graph.ii, ss.factor_graph.ii) and torch.equal(sl.factor_graph.jj, ss.factor_graph.jj)
 
 
 def test_relocalisation(device):
