@@ -41,7 +41,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     const bool narrow = a.N <= 128 || (a.N > 256 && a.N <= 384);   // a 256-wide tile would be >= 25 % padding
     if (narrow && blocks(256, 128) >= 128) cfg = 2128;
     else if (blocks(256, 256) >= 128) cfg = 2256;
-    else if (blocks(128, 128) >= 300) cfg = 1282;
+    else if (blocks(128, 128) >= 256) cfg = 1282;   // one block per CU at least (same-box A/B in situ: tools/batch_time.py)
     else if (blocks(64, 64) >= 512) cfg = 642;
     else if (a.K >= 2048) cfg = 644;
     else cfg = 643;
