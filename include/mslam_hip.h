@@ -250,6 +250,10 @@ int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, const float* 
  * 2 ReLU; out f32 or bf16.  K % 8 == 0. */
 int mslam_gemm_bf16(const void* A, const void* W, const float* bias, const void* residual_f32, void* out,
                     int M, int N, int K, int act, int out_is_bf16, void* stream);
+/* Tuning hook: force the tile configuration (codes in csrc/gemm.hip: 642 ... 2256; 0 = back to the built-in choice)
+ * for every plain GEMM of exactly this shape, process-wide.  tools/insitu_tune.py uses it to time whole network
+ * stages under alternative tilings; results do not depend on the tiling (same K order per output element). */
+int mslam_gemm_tile_override(int M, int N, int K, int cfg);
 /* NHWC bf16 conv (ks 1|3, stride 1|2, pad ks/2), W bf16 [Cout, ks*ks*Cin] tap-major; optional ReLU on
  * the input, act on the output, bf16 residual added after act. */
 int mslam_conv2d_nhwc_bf16(const void* in, const void* W, const float* bias, const void* residual_bf16,

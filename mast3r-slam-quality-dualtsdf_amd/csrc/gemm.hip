@@ -1,5 +1,7 @@
 // Host-side dispatch of the bf16 MFMA GEMM (kernel: gemm_kernel.h, instantiations: gemm_t*.hip).
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 #include "common.h"
 #include "gemm.h"
 
@@ -9,6 +11,23 @@ int launch_gemm_t64(const GemmArgs& a, int stages, hipStream_t s);
 int launch_gemm_t128(const GemmArgs& a, int waves, int stages, hipStream_t s);
 int launch_gemm_t128x64(const GemmArgs& a, int stages, hipStream_t s);
 int launch_gemm_t256(const GemmArgs& a, int bn, hipStream_t s);
+
+// Per-shape tile choices for plain (non-conv, ungrouped) problems: the measured table below, editable at run time
+// through mslam_gemm_tile_override (tools/insitu_tune.py finds the entries by timing whole network stages).
+static std::mutex g_tile_mu;
+static inline uint64_t tile_key(int M, int N, int K) { return (uint64_t)M | ((uint64_t)N << 22) | ((uint64_t)K << 44); }
+// measured in situ (tools/insitu_tune.py, profiles/r01_insitu_tune.log): shapes where the rule below is not the best
+static std::unordered_map<uint64_t, int> g_tile_override = {
+    {tile_key(3072, 3072, 1024), 1262},   // encoder qkv at a frame group of 4: 128x64 tiles instead of 144 tiles of 256x256
+    {tile_key(3072, 768, 3072), 643},     // decoder fc2 at a frame group of 4: ring of 3
+};
+
+int gemm_tile_override(int M, int N, int K, int cfg) {
+  std::lock_guard<std::mutex> lk(g_tile_mu);
+  if (cfg > 0) g_tile_override[tile_key(M, N, K)] = cfg;
+  else g_tile_override.erase(tile_key(M, N, K));
+  return 0;
+}
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   MSLAM_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %dx%dx%d", a.M, a.N, a.K);
@@ -37,6 +56,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   const long ngrp = a.groups > 1 ? 2 : 1;
   auto blocks = [&](int bm, int bn) { return ngrp * ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int cfg = forced;
+  if (cfg < 0 && !a.a_conv && a.groups <= 1) {
+    std::lock_guard<std::mutex> lk(g_tile_mu);
+    auto it = g_tile_override.find(tile_key(a.M, a.N, a.K));
+    if (it != g_tile_override.end()) cfg = it->second;
+  }
   if (cfg < 0) {
     const bool narrow = a.N <= 128 || (a.N > 256 && a.N <= 384);   // a 256-wide tile would be >= 25 % padding
     if (narrow && blocks(256, 128) >= 128) cfg = 2128;

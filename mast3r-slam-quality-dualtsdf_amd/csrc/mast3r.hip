@@ -1160,6 +1160,11 @@ extern "C" int mslam_mast3r_decode(void* handle, const float* feat1, const float
 }
 
 // ---- kernel-level entry points (unit tests, roofline measurement) -------------------------------
+extern "C" int mslam_gemm_tile_override(int M, int N, int K, int cfg) {
+  MSLAM_REQUIRE(M > 0 && N > 0 && K > 0 && cfg >= 0, "gemm_tile_override: bad arguments");
+  return gemm_tile_override(M, N, K, cfg);
+}
+
 extern "C" int mslam_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* residual_f32, void* out,
                                int M, int N, int K, int act, int out_is_bf16, void* stream) {
   MSLAM_REQUIRE(A && Wt && out, "gemm_bf16: null pointer");

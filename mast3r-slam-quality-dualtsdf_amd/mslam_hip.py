@@ -41,6 +41,7 @@ _SIGNATURES = {
     "mslam_mast3r_encode": [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_size, _c_vp],
     "mslam_mast3r_decode": [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int] + [_c_vp] * 10 + [_c_vp, _c_size, _c_vp],
     "mslam_gemm_bf16": [_c_vp] * 5 + [_c_int] * 5 + [_c_vp],
+    "mslam_gemm_tile_override": [_c_int] * 4,
     "mslam_conv2d_nhwc_bf16": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
     "mslam_attention_bf16": [_c_vp] * 4 + [_c_int] * 4 + [_c_vp],
     "mslam_layernorm_f32": [_c_vp] * 5 + [_c_int, _c_int, _c_float, _c_vp],

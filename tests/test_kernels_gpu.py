@@ -40,6 +40,29 @@ def test_gemm_bf16(device, M, N, K, act, out_bf16):
     assert _rel(out.float(), ref) <= (5e-3 if out_bf16 else 2e-3), _rel(out.float(), ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(3072, 3072, 1024), (3072, 768, 3072), (1000, 200, 520)])
+def test_gemm_result_does_not_depend_on_the_tile(device, M, N, K):
+    """Every tile configuration accumulates an output element over K in the same order, so the choice (heuristic,
+    measured table, mslam_gemm_tile_override) never changes a bit of the result - what makes batched network calls
+    bit-identical to one-frame calls."""
+    m = _lib()
+    g = torch.Generator().manual_seed(5)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).to(torch.bfloat16).to(device)
+    Wt = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).to(torch.bfloat16).to(device)
+    bias = (torch.rand(N, generator=g) - 0.5).to(device)
+    outs = []
+    try:
+        for cfg in (0, 642, 643, 644, 1262, 1263, 1242, 1282, 1283, 2128, 2256):
+            m.check(m.lib().mslam_gemm_tile_override(M, N, K, cfg), "override")
+            out = torch.empty((M, N), dtype=torch.float32, device=device)
+            m.check(m.lib().mslam_gemm_bf16(m.ptr(A), m.ptr(Wt), m.ptr(bias), 0, m.ptr(out), M, N, K, 1, 0, m.stream_ptr()), "gemm")
+            outs.append(out)
+    finally:
+        m.lib().mslam_gemm_tile_override(M, N, K, 0)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride", [(1, 24, 32, 768, 256, 3, 1), (2, 12, 16, 96, 256, 3, 1),
                                                        (1, 24, 32, 768, 768, 3, 2), (2, 24, 32, 1024, 96, 1, 1),
                                                        (1, 96, 128, 256, 128, 3, 1), (1, 9, 13, 64, 40, 3, 1)])
