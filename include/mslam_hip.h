@@ -251,7 +251,7 @@ int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, const float* 
 int mslam_gemm_bf16(const void* A, const void* W, const float* bias, const void* residual_f32, void* out,
                     int M, int N, int K, int act, int out_is_bf16, void* stream);
 /* Tuning hook: force the tile configuration (codes in csrc/gemm.hip: 642 ... 2256; 0 = back to the built-in choice)
- * for every plain GEMM of exactly this shape, process-wide.  tools/insitu_tune.py uses it to time whole network
+ * for every plain GEMM of exactly this shape (M < 0: the implicit-conv GEMM of shape |M| x N x K), process-wide.  tools/insitu_tune.py uses it to time whole network
  * stages under alternative tilings; results do not depend on the tiling (same K order per output element). */
 int mslam_gemm_tile_override(int M, int N, int K, int cfg);
 /* NHWC bf16 conv (ks 1|3, stride 1|2, pad ks/2), W bf16 [Cout, ks*ks*Cin] tap-major; optional ReLU on

@@ -63,6 +63,6 @@ struct GemmArgs {
 constexpr int kGemmPrefetchBlocks = 64;   // x 256+ lanes x 16 loads x 16 B = 4 MiB in flight
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
-int gemm_tile_override(int M, int N, int K, int cfg);   // cfg codes of gemm.hip; 0 removes the entry
+int gemm_tile_override(int M, int N, int K, int cfg, bool conv);   // cfg codes of gemm.hip; 0 removes the entry
 
 }  // namespace mslam

@@ -15,17 +15,20 @@ int launch_gemm_t256(const GemmArgs& a, int bn, hipStream_t s);
 // Per-shape tile choices for plain (non-conv, ungrouped) problems: the measured table below, editable at run time
 // through mslam_gemm_tile_override (tools/insitu_tune.py finds the entries by timing whole network stages).
 static std::mutex g_tile_mu;
-static inline uint64_t tile_key(int M, int N, int K) { return (uint64_t)M | ((uint64_t)N << 22) | ((uint64_t)K << 44); }
+static inline uint64_t tile_key(int M, int N, int K, bool conv = false) {   // M < 2^22, N < 2^20, K < 2^20
+  return (uint64_t)M | ((uint64_t)N << 22) | ((uint64_t)K << 42) | ((uint64_t)conv << 63);
+}
 // measured in situ (tools/insitu_tune.py, profiles/r01_insitu_tune.log): shapes where the rule below is not the best
 static std::unordered_map<uint64_t, int> g_tile_override = {
     {tile_key(3072, 3072, 1024), 1262},   // encoder qkv at a frame group of 4: 128x64 tiles instead of 144 tiles of 256x256
     {tile_key(3072, 768, 3072), 643},     // decoder fc2 at a frame group of 4: ring of 3
+    {tile_key(6144, 3072, 768), 1282},    // decoder fc1 of the batch-8 backend call: 288 tiles of 256x256 leave a half-empty round
 };
 
-int gemm_tile_override(int M, int N, int K, int cfg) {
+int gemm_tile_override(int M, int N, int K, int cfg, bool conv) {
   std::lock_guard<std::mutex> lk(g_tile_mu);
-  if (cfg > 0) g_tile_override[tile_key(M, N, K)] = cfg;
-  else g_tile_override.erase(tile_key(M, N, K));
+  if (cfg > 0) g_tile_override[tile_key(M, N, K, conv)] = cfg;
+  else g_tile_override.erase(tile_key(M, N, K, conv));
   return 0;
 }
 
@@ -56,10 +59,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   const long ngrp = a.groups > 1 ? 2 : 1;
   auto blocks = [&](int bm, int bn) { return ngrp * ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int cfg = forced;
-  if (cfg < 0 && !a.a_conv && a.groups <= 1) {
+  if (cfg < 0 && a.groups <= 1 && a.M < (1 << 22) && a.N < (1 << 20) && a.K < (1 << 20)) {
+    static const bool log_shapes = getenv("MSLAM_GEMM_LOG") != nullptr;   // one stderr line per new shape (tuning)
+    static std::unordered_map<uint64_t, int> seen;
     std::lock_guard<std::mutex> lk(g_tile_mu);
-    auto it = g_tile_override.find(tile_key(a.M, a.N, a.K));
+    const uint64_t key = tile_key(a.M, a.N, a.K, a.a_conv != 0);
+    auto it = g_tile_override.find(key);
     if (it != g_tile_override.end()) cfg = it->second;
+    if (log_shapes && seen.emplace(key, 1).second) fprintf(stderr, "mslam_gemm_shape conv=%d %d %d %d\n", (int)(a.a_conv != 0), a.M, a.N, a.K);
   }
   if (cfg < 0) {
     const bool narrow = a.N <= 128 || (a.N > 256 && a.N <= 384);   // a 256-wide tile would be >= 25 % padding

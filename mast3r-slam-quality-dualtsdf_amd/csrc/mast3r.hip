@@ -1161,8 +1161,8 @@ extern "C" int mslam_mast3r_decode(void* handle, const float* feat1, const float
 
 // ---- kernel-level entry points (unit tests, roofline measurement) -------------------------------
 extern "C" int mslam_gemm_tile_override(int M, int N, int K, int cfg) {
-  MSLAM_REQUIRE(M > 0 && N > 0 && K > 0 && cfg >= 0, "gemm_tile_override: bad arguments");
-  return gemm_tile_override(M, N, K, cfg);
+  MSLAM_REQUIRE(M != 0 && N > 0 && K > 0 && cfg >= 0, "gemm_tile_override: bad arguments");
+  return gemm_tile_override(M < 0 ? -M : M, N, K, cfg, M < 0);
 }
 
 extern "C" int mslam_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* residual_f32, void* out,

@@ -1,23 +1,23 @@
 #!/usr/bin/env python3
-"""In-situ tile tuning: for every plain GEMM shape of the network at a frame group of 4 (M = 3072) and at the batch-8
-backend call (M = 6144), time the WHOLE stage that contains it (encode / pair decode) under each tile configuration
-(mslam_gemm_tile_override) and keep the best - isolated warm loops over one shape mispredict.  Prints
-`M N K cfg stage_ms_before stage_ms_after` for every shape whose best differs from the built-in choice."""
-import os, sys
+"""In-situ tile tuning: for every GEMM / implicit-conv shape the network launches at a frame group of 4 and at the
+batch-8 backend call, time the WHOLE stage that contains it (encode / pair decode) under each tile configuration
+(mslam_gemm_tile_override) and keep the best - isolated warm loops over one shape mispredict.
+The shapes are discovered by a child process run with MSLAM_GEMM_LOG=1.  Prints one line per shape; `BEST` lines are
+the candidates for the measured table in csrc/gemm.hip (re-check them against the noise before adopting)."""
+import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mast3r-slam-quality-dualtsdf_amd")]
 import torch
 import mslam_hip as m
 from mast3r_slam.mast3r_model import Mast3rConfig, Mast3rHIP, random_state_dict
 
+PLAN = [("enc", 4), ("dec", 4), ("dec", 8)]
+H, W = 384, 512
+CFGS = [642, 643, 644, 1262, 1263, 1242, 1282, 1283, 2128, 2256]
 dev = torch.device("cuda:0")
 mc = Mast3rConfig()
 model = Mast3rHIP(random_state_dict(mc, seed=0), mc, device=dev)
-H, W = 384, 512
 L = m.lib()
-CFGS = [642, 643, 644, 1262, 1263, 1242, 1282, 1283, 2128, 2256]
-ENC = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096), (1024, 768)]
-DEC = [(768, 1024), (2304, 768), (768, 768), (1536, 768), (3072, 768), (768, 3072), (7168, 1792), (6400, 7168)]
 
 
 def stage(kind, B):
@@ -26,6 +26,15 @@ def stage(kind, B):
         return lambda: model._encode_image(img)
     f = torch.randn(B, 768, mc.enc_dim, device=dev)
     return lambda: model.decode_pair(f, f, H, W)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--list":
+    for kind, B in PLAN:
+        torch.cuda.synchronize()
+        print(f"mslam_stage {kind} {B}", file=sys.stderr, flush=True)
+        stage(kind, B)()
+        torch.cuda.synchronize()
+    sys.exit(0)
 
 
 def timeit(fn, n=6, reps=3):
@@ -42,27 +51,36 @@ def timeit(fn, n=6, reps=3):
     return best
 
 
-plan = [("enc", 4, ENC), ("dec", 4, DEC), ("dec", 8, DEC)]
-B_only = [int(a) for a in sys.argv[1:]] or None
-for kind, B, shapes in plan:
-    if B_only and B not in B_only:
-        continue
+child = subprocess.run([sys.executable, os.path.abspath(__file__), "--list"], env=dict(os.environ, MSLAM_GEMM_LOG="1"),
+                       stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True, check=True)
+shapes, cur = {}, None
+for ln in child.stderr.splitlines():
+    p = ln.split()
+    if p[:1] == ["mslam_stage"]:
+        cur = (p[1], int(p[2]))
+        shapes[cur] = []
+    elif p[:1] == ["mslam_gemm_shape"] and cur is not None:
+        shapes[cur].append((int(p[1][5:]), int(p[2]), int(p[3]), int(p[4])))
+seen_before = set()
+for kind, B in PLAN:
     fn = stage(kind, B)
     fn(); fn()
-    M = 768 * B
-    for N, K in shapes:
+    for conv, M, N, K in shapes[(kind, B)]:
+        if (conv, M, N, K) in seen_before or 2.0 * M * N * K < 2e9:   # tuned in an earlier stage / too small to matter
+            continue
+        seen_before.add((conv, M, N, K))
+        Ms = -M if conv else M
         base = timeit(fn)
         best_cfg, best_t = 0, base
         for cfg in CFGS:
-            L.mslam_gemm_tile_override(M, N, K, cfg)
+            L.mslam_gemm_tile_override(Ms, N, K, cfg)
             try:
                 fn()
                 t = timeit(fn)
             except Exception:
                 t = 1e9
-            if t < best_t * 0.995:
+            if t < best_t * 0.99:
                 best_cfg, best_t = cfg, t
-        L.mslam_gemm_tile_override(M, N, K, best_cfg)
-        tag = "KEEP" if best_cfg == 0 else "BEST"
-        print(f"{tag} {kind}{B} {M} {N} {K} cfg {best_cfg} stage {base:.3f} -> {best_t:.3f} ms", flush=True)
+        L.mslam_gemm_tile_override(Ms, N, K, best_cfg)
+        print(f"{'KEEP' if best_cfg == 0 else 'BEST'} {kind}{B} conv={conv} {M} {N} {K} cfg {best_cfg} stage {base:.3f} -> {best_t:.3f} ms", flush=True)
     print(f"== {kind}{B} final {timeit(fn):.3f} ms", flush=True)
