@@ -12,6 +12,8 @@ import mslam_hip as m
 from mast3r_slam.mast3r_model import Mast3rConfig, Mast3rHIP, random_state_dict
 
 PLAN = [("enc", 4), ("dec", 4), ("dec", 8)]
+if os.environ.get("MSLAM_TUNE_PLAN"):   # e.g. "enc:1 enc:2 enc:3 dec:3"
+    PLAN = [(t.split(":")[0], int(t.split(":")[1])) for t in os.environ["MSLAM_TUNE_PLAN"].split()]
 H, W = 384, 512
 CFGS = [642, 643, 644, 1262, 1263, 1242, 1282, 1283, 2128, 2256]
 dev = torch.device("cuda:0")
