@@ -462,6 +462,7 @@ struct Mast3rModel {
   bool two_streams = true;
   int fork_max_rows = 1 << 30;           // MSLAM_FORK_MAX_M: calls with more token rows per side stay on one queue
   bool dec_grouped = true;               // both decoder sides per launch (MSLAM_DEC_GROUPED=0: one queue per side)
+  int group_max_rows = 1024;             // ... up to this many token rows per side (MSLAM_GROUP_MAX_M), two queues above (measured)
   mutable std::mutex fork_mu;
   mutable std::map<hipStream_t, Fork*> forks;
   Fork* fork_for(hipStream_t caller, int& rc) const {
@@ -949,7 +950,7 @@ static void decode(Ctx& c, const float* feat1, const float* feat2, int B, int H,
   }
   // grouping pays while one side alone does not fill the chip (measured: 3.42 -> 3.29 ms at one image per side,
   // 7.7 -> 8.1 ms at four)
-  if (m.dec_grouped && M <= 2048) {
+  if (m.dec_grouped && M <= m.group_max_rows) {
     // ---- both sides per launch, one queue (heads fork below) ----------------------------------------
     cast_bf16(c, feat[0], fb[0], ME);
     cast_bf16(c, feat[1], fb[1], ME);
@@ -1086,6 +1087,7 @@ extern "C" int mslam_mast3r_create(void** handle_out, const int* cfg9, void* con
   if (const char* e = getenv("MSLAM_FORK_MAX_M")) m->fork_max_rows = atoi(e);
   if (const char* e = getenv("MSLAM_PREFETCH")) m->prefetch = atoi(e) != 0;
   if (const char* e = getenv("MSLAM_DEC_GROUPED")) m->dec_grouped = atoi(e) != 0;
+  if (const char* e = getenv("MSLAM_GROUP_MAX_M")) m->group_max_rows = atoi(e);
   if (rc) { delete m; return rc; }
   *handle_out = m;
   return MSLAM_OK;
