@@ -82,12 +82,15 @@ int mslam_pixel_to_lin(const int64_t* p1, int64_t* idx, int b, int n, int w, voi
  * Cs f32[P,HW,1], ii/jj i64[E] (global keyframe ids; the callee maps them to rows with
  * unique+searchsorted and pins the first unique id, gn_kernels.cu:161-170,1157),
  * idx_ii2jj i64[E,HW], valid_match u8[E,HW,1], Q f32[E,HW,1], K f32[3,3] (device), dx f32[P-1,7].
- * `workspace` is a caller-owned device buffer of >= mslam_gn_workspace_bytes(P,E,HW) bytes.
+ * `workspace` is a caller-owned device buffer of >= mslam_gn_workspace_bytes(P,E,HW,E_local) bytes
+ * (E_local = the edges this caller compacts and accumulates: E for the fused entry points, the size of
+ * the rank's edge slice in the sharded loop).  No cap on P: the fp64 normal equations are a dense
+ * (7(P-1))^2 matrix in the workspace, factored by a blocked LL^T on the f64 matrix cores.
  * The whole GN loop is enqueued on `stream` with NO host synchronisation: convergence
  * (||dx|| < delta_thresh, gn_kernels.cu:1219-1222) is a device-side flag that turns the remaining
  * iterations' kernels into no-ops.  LLT failure => dx = 0 (gn_kernels.cu:147-150).
  * ------------------------------------------------------------------------------------------ */
-size_t mslam_gn_workspace_bytes(int num_poses, int num_edges, int num_points);
+size_t mslam_gn_workspace_bytes(int num_poses, int num_edges, int num_points, int local_edges);
 
 /* Replaces gauss_newton_rays (gn.cpp:28-52; ray_align_kernel gn_kernels.cu:813-1138). */
 int mslam_gauss_newton_rays(float* Twc, const float* Xs, const float* Cs, const int64_t* ii,
@@ -115,19 +118,24 @@ int mslam_gauss_newton_points(float* Twc, const float* Xs, const float* Cs, cons
                               void* stream);
 
 /* The same loop opened up for the multi-GPU factor graph (global_opt.py:123-223): every rank calls
- * begin() with the FULL edge list, accumulate() for ITS edge range (per-edge inputs are local arrays
- * of edge_count rows; Hs f32[4,E,7,7] / gs f32[2,E,7] are the global, reference-layout buffers
- * [ii,ij,ji,jj] / [i,j], gn_kernels.cu:1120-1133), all-reduces Hs and gs (RCCL sum; slots of other
- * ranks' edges are zero), then solve_retract(), which is bit-identical on every rank.
+ * begin() with the FULL edge list, then compact() ONCE for ITS edge range (per-edge inputs are local
+ * arrays of edge_count rows): the pose-independent part of the reference's edge kernels - the gather
+ * Xi[idx] and the gates valid_match, Q > Q_thresh, C > C_thresh (gn_kernels.cu:905-925) - is resolved
+ * into a dense stream in the workspace.  Per iteration: accumulate() streams it at the current poses
+ * into the global, reference-layout buffers Hs f32[4,E,7,7] / gs f32[2,E,7] ([ii,ij,ji,jj] / [i,j],
+ * gn_kernels.cu:1120-1133; slots of other ranks' edges stay zero), the caller all-reduces Hs and gs
+ * (RCCL sum), then solve_retract(), which is bit-identical on every rank.
  * kind: 0 rays (sigma_a=ray, sigma_b=dist), 1 calib (pixel, depth), 2 points (point, -). */
 int mslam_gn_begin(const int64_t* ii, const int64_t* jj, int num_poses, int num_edges, int num_points,
                    void* workspace, size_t workspace_bytes, void* stream);
-int mslam_gn_accumulate(int kind, const float* Twc, const float* Xs, const float* Cs, const float* K,
-                        const int64_t* idx_ii2jj, const uint8_t* valid_match, const float* Q,
-                        int num_poses, int num_points, int num_edges, int edge_begin, int edge_count,
-                        float sigma_a, float sigma_b, float C_thresh, float Q_thresh, int height,
-                        int width, int pixel_border, float z_eps, float* Hs, float* gs, void* workspace,
-                        size_t workspace_bytes, void* stream);
+int mslam_gn_compact(const float* Xs, const float* Cs, const int64_t* idx_ii2jj, const uint8_t* valid_match,
+                     const float* Q, int num_poses, int num_points, int num_edges, int edge_begin,
+                     int edge_count, float C_thresh, float Q_thresh, void* workspace, size_t workspace_bytes,
+                     void* stream);
+int mslam_gn_accumulate(int kind, const float* Twc, const float* K, int num_poses, int num_points,
+                        int num_edges, int edge_begin, int edge_count, float sigma_a, float sigma_b,
+                        int height, int width, int pixel_border, float z_eps, float* Hs, float* gs,
+                        void* workspace, size_t workspace_bytes, void* stream);
 int mslam_gn_solve_retract(const float* Hs, const float* gs, int num_poses, int num_edges,
                            int num_points, float* Twc, float* dx, float delta_thresh, void* workspace,
                            size_t workspace_bytes, void* stream);

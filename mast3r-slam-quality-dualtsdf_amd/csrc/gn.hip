@@ -1,6 +1,6 @@
 // Gauss-Newton backend for gfx950: per-edge residual/JtJ accumulation (rays | calib | points),
-// fp64 normal-equation assembly, blocked dense fp64 Cholesky, Sim3 retraction — all on the
-// device, no host round trip and no host synchronisation inside the GN loop.
+// fp64 normal-equation assembly, blocked dense fp64 Cholesky on the f64 matrix cores, Sim3
+// retraction - all on the device, no host round trip and no host synchronisation inside the loop.
 //
 // Reference behaviour reproduced (re-designed, not translated):
 //   ray_align_kernel / calib_proj_kernel / point_align_kernel
@@ -9,70 +9,78 @@
 //   get_unique_kf_idx / create_inds                        gn_kernels.cu:161-170
 //   pose_retr_kernel                                        gn_kernels.cu:415-453
 //
-// MI355X-first design decisions:
+// MI355X-first design decisions (DESIGN.md "GN"):
 //   * apply_Sim3_adj_inv is linear: Jj = M_i x with a per-edge 7x7 matrix M_i, and Ji = -Jj.
 //     So the 14x14 block Hessian is [[A,-A],[-A,A]] with A = M (sum w x x^T) M^T.  The streaming
 //     kernel accumulates only B = sum w x x^T (28 values) and u = sum w e x (7 values) of the RAW
 //     (pre-adjoint) Jacobian rows - 35 accumulators per lane instead of 119, and no quaternion
 //     algebra per residual row.  M is applied once per edge, in fp64, in the reduce kernel.
-//   * every edge is split over several workgroups (>= 1k workgroups per launch instead of one
-//     256-thread block per edge), wave64 shuffle reduction + one LDS pass, partials combined in
-//     a fixed order (deterministic, no atomics).
-//   * the fp64 solve never leaves the GPU: assemble -> right-looking blocked LL^T on the
-//     augmented matrix [H | b] (forward substitution comes for free) -> blocked back substitution
-//     -> dx = -x -> retraction -> ||dx|| test sets a device-side `done` flag that later
-//     iterations' kernels read and exit on (replaces delta_norm.item(), gn_kernels.cu:1219-1222).
+//   * the match data of an edge (idx, valid, Q) and the pointmaps / confidences do not change
+//     during the <= 10 iterations of one call - only the poses do.  gn_compact therefore resolves
+//     the gather Xi[idx], applies the pose-independent gates (valid_match, Q > Q_thresh,
+//     C > C_thresh) ONCE and writes the surviving points as a dense struct-of-arrays stream
+//     (28 B per point for rays/points, 32 B for calib); every iteration then streams that with
+//     16-B loads and no gather instead of re-reading 45 B per point through an index
+//     (HBM is plentiful on this part: 288 GB buys the stream for thousands of edges).
+//   * every edge is split over several workgroups (>= 1k workgroups per launch), wave64 shuffle
+//     reduction + one LDS pass, partials combined in a fixed order (deterministic, no atomics).
+//   * the fp64 solve never leaves the GPU and has no size cap: assemble (one wave per pose
+//     block-row) -> right-looking blocked LL^T on the augmented matrix [H | b] (forward
+//     substitution comes for free), ONE launch per panel: the trailing update runs on
+//     v_mfma_f64_16x16x4_f64 in 64x64 tiles and the workgroups that own the next panel's columns
+//     factor its diagonal block (redundantly, in LDS) and solve their rows of it in the same
+//     launch -> multi-workgroup blocked back substitution -> dx = -x -> retraction -> ||dx|| test
+//     sets a device-side `done` flag that later iterations' kernels read and exit on (replaces
+//     delta_norm.item(), gn_kernels.cu:1219-1222).
 #include "common.h"
 #include "sim3.h"
 
 namespace mslam {
 
-constexpr int kAcc = 35;      // 28 (lower triangle of 7x7) + 7
+constexpr int kAcc = 35;        // 28 (lower triangle of 7x7) + 7
 constexpr int kEdgeConst = 16;  // sR_ij (9) + t_ij (3) + pad
-constexpr int kNB = 32;       // Cholesky panel width
+constexpr int kPlanes = 8;      // compact stream: xi(3) xj(3) sqrt(q) ind
+constexpr int kTile = 64;       // Cholesky trailing-update tile
 
 struct GnState {
-  int done;        // ||dx|| < delta_thresh reached (or LLT failure): later launches are no-ops
+  int done;        // ||dx|| < delta_thresh reached: later launches are no-ops
   int iters;       // GN iterations actually executed
   int chol_fail;   // current factorisation hit a non-positive pivot (Eigen: info() != Success)
   float last_norm;
 };
 
 // ---------------------------------------------------------------------------------------------
-// index preparation: unique(sorted) + searchsorted, O(E^2) in one workgroup (E <= a few thousand)
+// index preparation: unique(sorted) + searchsorted by brute force, one thread per entry
+// (2E entries, each scanned against all 2E: L2-resident, two short launches per GN call)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_index_kernel(const int64_t* __restrict__ ii,
+__device__ __forceinline__ int64_t ij_val(const int64_t* ii, const int64_t* jj, int E, int k) {
+  return k < E ? ii[k] : jj[k - E];
+}
+
+__global__ __launch_bounds__(256) void gn_first_kernel(const int64_t* __restrict__ ii,
                                                        const int64_t* __restrict__ jj, int E,
-                                                       int num_fix, int* __restrict__ ii_edge,
-                                                       int* __restrict__ jj_edge, int* __restrict__ ii_opt,
-                                                       int* __restrict__ jj_opt, int* __restrict__ first,
-                                                       int* __restrict__ num_unique) {
-  const int n2 = 2 * E;
-  auto val = [&](int k) -> int64_t { return k < E ? ii[k] : jj[k - E]; };
-  __shared__ int cnt;
-  if (threadIdx.x == 0) cnt = 0;
-  // phase 1: first-occurrence flags
-  int local_unique = 0;
-  for (int k = threadIdx.x; k < n2; k += 256) {
-    const int64_t v = val(k);
-    int f = 1;
-    for (int m = 0; m < k; m++)
-      if (val(m) == v) { f = 0; break; }
-    first[k] = f;
-    local_unique += f;
-  }
-  __syncthreads();
-  atomicAdd(&cnt, local_unique);
-  // phase 2: rank = number of DISTINCT values smaller than v  (== searchsorted into unique())
-  for (int k = threadIdx.x; k < n2; k += 256) {
-    const int64_t v = val(k);
-    int rank = 0;
-    for (int m = 0; m < n2; m++) rank += (first[m] && val(m) < v) ? 1 : 0;
-    if (k < E) { ii_edge[k] = rank; ii_opt[k] = rank - num_fix; }
-    else { jj_edge[k - E] = rank; jj_opt[k - E] = rank - num_fix; }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) *num_unique = cnt;
+                                                       int* __restrict__ first) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= 2 * E) return;
+  const int64_t v = ij_val(ii, jj, E, k);
+  int f = 1;
+  for (int m = 0; m < k; m++)
+    if (ij_val(ii, jj, E, m) == v) { f = 0; break; }
+  first[k] = f;
+}
+
+__global__ __launch_bounds__(256) void gn_rank_kernel(const int64_t* __restrict__ ii,
+                                                      const int64_t* __restrict__ jj, int E, int num_fix,
+                                                      const int* __restrict__ first,
+                                                      int* __restrict__ ii_edge, int* __restrict__ jj_edge,
+                                                      int* __restrict__ ii_opt, int* __restrict__ jj_opt) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= 2 * E) return;
+  const int64_t v = ij_val(ii, jj, E, k);
+  int rank = 0;  // number of DISTINCT values smaller than v  (== searchsorted into unique())
+  for (int m = 0; m < 2 * E; m++) rank += (first[m] && ij_val(ii, jj, E, m) < v) ? 1 : 0;
+  if (k < E) { ii_edge[k] = rank; ii_opt[k] = rank - num_fix; }
+  else { jj_edge[k - E] = rank; jj_opt[k - E] = rank - num_fix; }
 }
 
 // per-edge constants: T_ij = Ti^-1 * Tj as scaled rotation + translation (thread 0's relSim3 in the
@@ -93,6 +101,67 @@ __global__ void gn_edge_setup_kernel(const GnState* __restrict__ st, const float
   for (int k = 0; k < 9; k++) c[k] = Tij.s * R[k];
   c[9] = Tij.t[0]; c[10] = Tij.t[1]; c[11] = Tij.t[2];
   c[12] = c[13] = c[14] = c[15] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// compaction: one pass over the call's constant inputs
+// ---------------------------------------------------------------------------------------------
+// Workgroup (chunk, local edge) walks its chunk of the edge's points in order, 256 at a time, and
+// appends the points that pass the pose-independent gates to its slot of the stream (order
+// preserved: deterministic).  Slot layout: kPlanes planes of chunk_len floats.
+__global__ __launch_bounds__(256) void gn_compact_kernel(
+    const float* __restrict__ Xs, const float* __restrict__ Cs, const int* __restrict__ ii_edge,
+    const int* __restrict__ jj_edge, const int64_t* __restrict__ idx_ii2jj,
+    const uint8_t* __restrict__ valid_match, const float* __restrict__ Q, int num_points, int chunk_len,
+    float C_thresh, float Q_thresh, float* __restrict__ stream, int* __restrict__ counts) {
+  const int e = blockIdx.y, chunk = blockIdx.x, S = gridDim.x;
+  const int ix = ii_edge[e], jx = jj_edge[e];
+  const float* __restrict__ Xi_base = Xs + (size_t)ix * num_points * 3;
+  const float* __restrict__ Xj_base = Xs + (size_t)jx * num_points * 3;
+  const float* __restrict__ Ci_base = Cs + (size_t)ix * num_points;
+  const float* __restrict__ Cj_base = Cs + (size_t)jx * num_points;
+  const int64_t* __restrict__ idx_e = idx_ii2jj + (size_t)e * num_points;
+  const uint8_t* __restrict__ vm_e = valid_match + (size_t)e * num_points;
+  const float* __restrict__ Q_e = Q + (size_t)e * num_points;
+  float* __restrict__ slot = stream + ((size_t)e * S + chunk) * (size_t)chunk_len * kPlanes;
+  __shared__ int wave_cnt[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int k_begin = chunk * chunk_len;
+  const int k_end = min(k_begin + chunk_len, num_points);
+  int base = 0;  // points emitted so far (uniform)
+  for (int k0 = k_begin; k0 < k_end; k0 += 256) {
+    const int k = k0 + (int)threadIdx.x;
+    bool valid = false;
+    long long ind = 0;
+    float q = 0.0f;
+    if (k < k_end) {
+      const bool vm = vm_e[k] != 0;
+      ind = vm ? idx_e[k] : 0;  // invalid matches read index 0 (gn_kernels.cu:914)
+      q = Q_e[k];
+      const float ci = Ci_base[ind], cj = Cj_base[k];
+      valid = vm & (q > Q_thresh) & (ci > C_thresh) & (cj > C_thresh);
+    }
+    const unsigned long long m = __ballot(valid);
+    if (lane == 0) wave_cnt[wid] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wid; w++) off += wave_cnt[w];
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (valid) {
+      const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+      slot[0 * (size_t)chunk_len + pos] = Xi_base[ind * 3 + 0];
+      slot[1 * (size_t)chunk_len + pos] = Xi_base[ind * 3 + 1];
+      slot[2 * (size_t)chunk_len + pos] = Xi_base[ind * 3 + 2];
+      slot[3 * (size_t)chunk_len + pos] = Xj_base[(size_t)k * 3 + 0];
+      slot[4 * (size_t)chunk_len + pos] = Xj_base[(size_t)k * 3 + 1];
+      slot[5 * (size_t)chunk_len + pos] = Xj_base[(size_t)k * 3 + 2];
+      slot[6 * (size_t)chunk_len + pos] = sqrtf(q);
+      slot[7 * (size_t)chunk_len + pos] = __int_as_float((int)ind);
+    }
+    base += total;
+    __syncthreads();  // wave_cnt is rewritten by the next round
+  }
+  if (threadIdx.x == 0) counts[e * S + chunk] = base;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -130,134 +199,140 @@ struct GnParams {
   const float* K;  // device f32[3,3] (calib only)
 };
 
+struct EdgeConst {
+  float r00, r01, r02, r10, r11, r12, r20, r21, r22, t0, t1, t2;
+};
+
+// one surviving point: the reference's residual rows and raw Jacobian rows (gn_kernels.cu:905-1010
+// rays, :1320-1420 calib, :540-600 points), weights = huber(sqrt_info * r) * info
+template <int KIND>
+__device__ __forceinline__ void gn_point(float (&acc)[kAcc], const EdgeConst& c, const GnParams& P, float xi0,
+                                         float xi1, float xi2, float xj0, float xj1, float xj2, float sq,
+                                         int ind) {
+  // X_j in frame i
+  const float p0 = fmaf(c.r00, xj0, fmaf(c.r01, xj1, fmaf(c.r02, xj2, c.t0)));
+  const float p1 = fmaf(c.r10, xj0, fmaf(c.r11, xj1, fmaf(c.r12, xj2, c.t1)));
+  const float p2 = fmaf(c.r20, xj0, fmaf(c.r21, xj1, fmaf(c.r22, xj2, c.t2)));
+  if constexpr (KIND == 0) {
+    const float n2i = fmaf(xi2, xi2, fmaf(xi1, xi1, xi0 * xi0));
+    const float n1i = sqrtf(n2i);
+    const float n1i_inv = 1.0f / n1i;
+    const float n2j = fmaf(p2, p2, fmaf(p1, p1, p0 * p0));
+    const float n1j = sqrtf(n2j);
+    const float n1j_inv = 1.0f / n1j;
+    const float rj0 = p0 * n1j_inv, rj1 = p1 * n1j_inv, rj2 = p2 * n1j_inv;
+    const float e0 = rj0 - xi0 * n1i_inv, e1 = rj1 - xi1 * n1i_inv, e2 = rj2 - xi2 * n1i_inv;
+    const float e3 = n1j - n1i;
+    const float swr = P.sa_inv * sq;
+    const float swd = P.sb_inv * sq;
+    const float wr = swr * swr, wd = swd * swd;
+    const float w0 = huber_w(swr * e0) * wr, w1 = huber_w(swr * e1) * wr, w2 = huber_w(swr * e2) * wr;
+    const float w3 = huber_w(swd * e3) * wd;
+    const float n3 = n1j_inv / n2j;
+    const float dxx = n1j_inv - p0 * p0 * n3, dyy = n1j_inv - p1 * p1 * n3, dzz = n1j_inv - p2 * p2 * n3;
+    const float dxy = -p0 * p1 * n3, dxz = -p0 * p2 * n3, dyz = -p1 * p2 * n3;
+    {
+      const float x[7] = {dxx, dxy, dxz, 0.0f, rj2, -rj1, 0.0f};
+      accum_row<0b0110111>(acc, x, w0, e0);
+    }
+    {
+      const float x[7] = {dxy, dyy, dyz, -rj2, 0.0f, rj0, 0.0f};
+      accum_row<0b0101111>(acc, x, w1, e1);
+    }
+    {
+      const float x[7] = {dxz, dyz, dzz, rj1, -rj0, 0.0f, 0.0f};
+      accum_row<0b0011111>(acc, x, w2, e2);
+    }
+    {
+      const float x[7] = {rj0, rj1, rj2, 0.0f, 0.0f, 0.0f, n1j};
+      accum_row<0b1000111>(acc, x, w3, e3);
+    }
+  } else if constexpr (KIND == 1) {
+    const float Pfx = P.K[0], Pfy = P.K[4], Pcx = P.K[2], Pcy = P.K[5];
+    const int u_t = ind % P.width, v_t = ind / P.width;
+    const bool valid_z = (p2 > P.z_eps) && (xi2 > P.z_eps);
+    const float zinv = valid_z ? 1.0f / p2 : 0.0f;
+    const float zj_log = valid_z ? logf(p2) : 0.0f;
+    const float zi_log = valid_z ? logf(xi2) : 0.0f;
+    const float xz = p0 * zinv, yz = p1 * zinv;
+    const float u = fmaf(Pfx, xz, Pcx), v = fmaf(Pfy, yz, Pcy);
+    const bool valid_u = (u > P.border_lo) && (u < P.border_hi_u);
+    const bool valid_v = (v > P.border_lo) && (v < P.border_hi_v);
+    const bool valid = valid_u & valid_v & valid_z;  // the pose-dependent gates stay per iteration
+    const float e0 = u - (float)u_t, e1 = v - (float)v_t, e2 = zj_log - zi_log;
+    const float swp = valid ? P.sa_inv * sq : 0.0f;
+    const float swd = valid ? P.sb_inv * sq : 0.0f;
+    const float wp = swp * swp, wd = swd * swd;
+    const float w0 = huber_w(swp * e0) * wp, w1 = huber_w(swp * e1) * wp, w2 = huber_w(swd * e2) * wd;
+    {
+      const float x[7] = {Pfx * zinv, 0.0f, -Pfx * xz * zinv, -Pfx * xz * yz, Pfx * (1.0f + xz * xz),
+                          -Pfx * yz, 0.0f};
+      accum_row<0b0111101>(acc, x, w0, e0);
+    }
+    {
+      const float x[7] = {0.0f, Pfy * zinv, -Pfy * yz * zinv, -Pfy * (1.0f + yz * yz), Pfy * xz * yz,
+                          Pfy * xz, 0.0f};
+      accum_row<0b0111110>(acc, x, w1, e1);
+    }
+    {
+      const float x[7] = {0.0f, 0.0f, zinv, yz, -xz, 0.0f, 1.0f};
+      accum_row<0b1011100>(acc, x, w2, e2);
+    }
+  } else {
+    const float e0 = p0 - xi0, e1 = p1 - xi1, e2 = p2 - xi2;
+    const float swp = P.sa_inv * sq;
+    const float wc = swp * swp;
+    const float w0 = huber_w(swp * e0) * wc, w1 = huber_w(swp * e1) * wc, w2 = huber_w(swp * e2) * wc;
+    {
+      const float x[7] = {1.0f, 0.0f, 0.0f, 0.0f, p2, -p1, p0};
+      accum_row<0b1110001>(acc, x, w0, e0);
+    }
+    {
+      const float x[7] = {0.0f, 1.0f, 0.0f, -p2, 0.0f, p0, p1};
+      accum_row<0b1101010>(acc, x, w1, e1);
+    }
+    {
+      const float x[7] = {0.0f, 0.0f, 1.0f, p1, -p0, 0.0f, p2};
+      accum_row<0b1011100>(acc, x, w2, e2);
+    }
+  }
+}
+
 template <int KIND>  // 0 rays, 1 calib, 2 points
-__global__ __launch_bounds__(256) void gn_accum_kernel(
-    const GnState* __restrict__ st, const float* __restrict__ econst, const float* __restrict__ Xs,
-    const float* __restrict__ Cs, const int* __restrict__ ii_edge, const int* __restrict__ jj_edge,
-    const int64_t* __restrict__ idx_ii2jj, const uint8_t* __restrict__ valid_match,
-    const float* __restrict__ Q, int num_points, int chunk_len, GnParams P, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void gn_accum_kernel(const GnState* __restrict__ st,
+                                                       const float* __restrict__ econst,
+                                                       const float* __restrict__ stream,
+                                                       const int* __restrict__ counts, int chunk_len,
+                                                       GnParams P, float* __restrict__ partial) {
   if (st->done) return;
-  const int e = blockIdx.y;
-  const int chunk = blockIdx.x;
-  const int S = gridDim.x;
+  const int e = blockIdx.y, chunk = blockIdx.x, S = gridDim.x;
   // wave-uniform per-edge constants -> scalar loads
-  const float* c = econst + (size_t)e * kEdgeConst;
-  const float r00 = c[0], r01 = c[1], r02 = c[2], r10 = c[3], r11 = c[4], r12 = c[5], r20 = c[6],
-              r21 = c[7], r22 = c[8], t0 = c[9], t1 = c[10], t2 = c[11];
-  const int ix = ii_edge[e], jx = jj_edge[e];
-  const float* __restrict__ Xi_base = Xs + (size_t)ix * num_points * 3;
-  const float* __restrict__ Xj_base = Xs + (size_t)jx * num_points * 3;
-  const float* __restrict__ Ci_base = Cs + (size_t)ix * num_points;
-  const float* __restrict__ Cj_base = Cs + (size_t)jx * num_points;
-  const int64_t* __restrict__ idx_e = idx_ii2jj + (size_t)e * num_points;
-  const uint8_t* __restrict__ vm_e = valid_match + (size_t)e * num_points;
-  const float* __restrict__ Q_e = Q + (size_t)e * num_points;
+  const float* cc = econst + (size_t)e * kEdgeConst;
+  const EdgeConst c = {cc[0], cc[1], cc[2], cc[3], cc[4], cc[5], cc[6], cc[7], cc[8], cc[9], cc[10], cc[11]};
+  const float* __restrict__ slot = stream + ((size_t)e * S + chunk) * (size_t)chunk_len * kPlanes;
+  const int n = counts[e * S + chunk];
 
   float acc[kAcc];
 #pragma unroll
   for (int l = 0; l < kAcc; l++) acc[l] = 0.0f;
 
-  const int k_begin = chunk * chunk_len;
-  const int k_end = min(k_begin + chunk_len, num_points);
-  for (int k = k_begin + (int)threadIdx.x; k < k_end; k += 256) {
-    const bool vm = vm_e[k] != 0;
-    const long long ind = vm ? idx_e[k] : 0;  // invalid matches read index 0 (gn_kernels.cu:914)
-    const float xj0 = Xj_base[(size_t)k * 3 + 0], xj1 = Xj_base[(size_t)k * 3 + 1], xj2 = Xj_base[(size_t)k * 3 + 2];
-    const float xi0 = Xi_base[ind * 3 + 0], xi1 = Xi_base[ind * 3 + 1], xi2 = Xi_base[ind * 3 + 2];
-    const float q = Q_e[k];
-    const float ci = Ci_base[ind];
-    const float cj = Cj_base[k];
-    bool valid = vm & (q > P.Q_thresh) & (ci > P.C_thresh) & (cj > P.C_thresh);
-
-    // X_j in frame i
-    const float p0 = fmaf(r00, xj0, fmaf(r01, xj1, fmaf(r02, xj2, t0)));
-    const float p1 = fmaf(r10, xj0, fmaf(r11, xj1, fmaf(r12, xj2, t1)));
-    const float p2 = fmaf(r20, xj0, fmaf(r21, xj1, fmaf(r22, xj2, t2)));
-
-    if constexpr (KIND == 0) {
-      const float n2i = fmaf(xi2, xi2, fmaf(xi1, xi1, xi0 * xi0));
-      const float n1i = sqrtf(n2i);
-      const float n1i_inv = 1.0f / n1i;
-      const float n2j = fmaf(p2, p2, fmaf(p1, p1, p0 * p0));
-      const float n1j = sqrtf(n2j);
-      const float n1j_inv = 1.0f / n1j;
-      const float rj0 = p0 * n1j_inv, rj1 = p1 * n1j_inv, rj2 = p2 * n1j_inv;
-      const float e0 = rj0 - xi0 * n1i_inv, e1 = rj1 - xi1 * n1i_inv, e2 = rj2 - xi2 * n1i_inv;
-      const float e3 = n1j - n1i;
-      const float sq = sqrtf(q);
-      const float swr = valid ? P.sa_inv * sq : 0.0f;
-      const float swd = valid ? P.sb_inv * sq : 0.0f;
-      const float wr = swr * swr, wd = swd * swd;
-      const float w0 = huber_w(swr * e0) * wr, w1 = huber_w(swr * e1) * wr, w2 = huber_w(swr * e2) * wr;
-      const float w3 = huber_w(swd * e3) * wd;
-      const float n3 = n1j_inv / n2j;
-      const float dxx = n1j_inv - p0 * p0 * n3, dyy = n1j_inv - p1 * p1 * n3, dzz = n1j_inv - p2 * p2 * n3;
-      const float dxy = -p0 * p1 * n3, dxz = -p0 * p2 * n3, dyz = -p1 * p2 * n3;
-      {
-        const float x[7] = {dxx, dxy, dxz, 0.0f, rj2, -rj1, 0.0f};
-        accum_row<0b0110111>(acc, x, w0, e0);
+  // four consecutive points per lane and round: one 16-B load per plane
+  for (int k = (int)threadIdx.x * 4; k < n; k += 1024) {
+    float f[kPlanes][4];
+#pragma unroll
+    for (int p = 0; p < kPlanes; p++) {
+      if (p < (KIND == 1 ? 8 : 7)) {
+        const float4 v = *reinterpret_cast<const float4*>(slot + (size_t)p * chunk_len + k);
+        f[p][0] = v.x; f[p][1] = v.y; f[p][2] = v.z; f[p][3] = v.w;
+      } else {
+        f[p][0] = f[p][1] = f[p][2] = f[p][3] = 0.0f;
       }
-      {
-        const float x[7] = {dxy, dyy, dyz, -rj2, 0.0f, rj0, 0.0f};
-        accum_row<0b0101111>(acc, x, w1, e1);
-      }
-      {
-        const float x[7] = {dxz, dyz, dzz, rj1, -rj0, 0.0f, 0.0f};
-        accum_row<0b0011111>(acc, x, w2, e2);
-      }
-      {
-        const float x[7] = {rj0, rj1, rj2, 0.0f, 0.0f, 0.0f, n1j};
-        accum_row<0b1000111>(acc, x, w3, e3);
-      }
-    } else if constexpr (KIND == 1) {
-      const float Pfx = P.K[0], Pfy = P.K[4], Pcx = P.K[2], Pcy = P.K[5];
-      const int u_t = (int)(ind % P.width), v_t = (int)(ind / P.width);
-      const bool valid_z = (p2 > P.z_eps) && (xi2 > P.z_eps);
-      const float zinv = valid_z ? 1.0f / p2 : 0.0f;
-      const float zj_log = valid_z ? logf(p2) : 0.0f;
-      const float zi_log = valid_z ? logf(xi2) : 0.0f;
-      const float xz = p0 * zinv, yz = p1 * zinv;
-      const float u = fmaf(Pfx, xz, Pcx), v = fmaf(Pfy, yz, Pcy);
-      const bool valid_u = (u > P.border_lo) && (u < P.border_hi_u);
-      const bool valid_v = (v > P.border_lo) && (v < P.border_hi_v);
-      valid = valid & valid_u & valid_v & valid_z;
-      const float e0 = u - (float)u_t, e1 = v - (float)v_t, e2 = zj_log - zi_log;
-      const float sq = sqrtf(q);
-      const float swp = valid ? P.sa_inv * sq : 0.0f;
-      const float swd = valid ? P.sb_inv * sq : 0.0f;
-      const float wp = swp * swp, wd = swd * swd;
-      const float w0 = huber_w(swp * e0) * wp, w1 = huber_w(swp * e1) * wp, w2 = huber_w(swd * e2) * wd;
-      {
-        const float x[7] = {Pfx * zinv, 0.0f, -Pfx * xz * zinv, -Pfx * xz * yz, Pfx * (1.0f + xz * xz),
-                            -Pfx * yz, 0.0f};
-        accum_row<0b0111101>(acc, x, w0, e0);
-      }
-      {
-        const float x[7] = {0.0f, Pfy * zinv, -Pfy * yz * zinv, -Pfy * (1.0f + yz * yz), Pfy * xz * yz,
-                            Pfy * xz, 0.0f};
-        accum_row<0b0111110>(acc, x, w1, e1);
-      }
-      {
-        const float x[7] = {0.0f, 0.0f, zinv, yz, -xz, 0.0f, 1.0f};
-        accum_row<0b1011100>(acc, x, w2, e2);
-      }
-    } else {
-      const float e0 = p0 - xi0, e1 = p1 - xi1, e2 = p2 - xi2;
-      const float swp = valid ? P.sa_inv * sqrtf(q) : 0.0f;
-      const float wc = swp * swp;
-      const float w0 = huber_w(swp * e0) * wc, w1 = huber_w(swp * e1) * wc, w2 = huber_w(swp * e2) * wc;
-      {
-        const float x[7] = {1.0f, 0.0f, 0.0f, 0.0f, p2, -p1, p0};
-        accum_row<0b1110001>(acc, x, w0, e0);
-      }
-      {
-        const float x[7] = {0.0f, 1.0f, 0.0f, -p2, 0.0f, p0, p1};
-        accum_row<0b1101010>(acc, x, w1, e1);
-      }
-      {
-        const float x[7] = {0.0f, 0.0f, 1.0f, p1, -p0, 0.0f, p2};
-        accum_row<0b1011100>(acc, x, w2, e2);
-      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (k + j < n)
+        gn_point<KIND>(acc, c, P, f[0][j], f[1][j], f[2][j], f[3][j], f[4][j], f[5][j], f[6][j],
+                       KIND == 1 ? __float_as_int(f[7][j]) : 0);
     }
   }
 
@@ -355,201 +430,296 @@ __global__ __launch_bounds__(64) void gn_reduce_kernel(const GnState* __restrict
 
 // ---------------------------------------------------------------------------------------------
 // fp64 normal equations: Haug is (np+1) x ld row-major; rows 0..np-1 = H (padded with identity),
-// row np = b^T.  One workgroup per pose block-row; edges visited in the reference's triplet order.
+// row np = b^T.  Haug is zeroed by the caller; ONE WAVE per pose block-row visits the edges in the
+// reference's triplet order (update_lhs / update_rhs, gn_kernels.cu:71-113, 1201-1206): 64 edges are
+// tested per step with a ballot, the matching 7x7 blocks are summed per column block in an LDS table
+// (first kTab distinct columns of the row; further ones fall back to read-modify-write of the row,
+// which this wave owns), the rhs block in registers.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_assemble_kernel(const GnState* __restrict__ st,
-                                                          const float* __restrict__ Hs,
-                                                          const float* __restrict__ gs,
-                                                          const int* __restrict__ ii_opt,
-                                                          const int* __restrict__ jj_opt, int E, int N,
-                                                          int np, int ld, double* __restrict__ Haug) {
+constexpr int kTab = 32;
+
+__global__ __launch_bounds__(64) void gn_assemble_kernel(const GnState* __restrict__ st,
+                                                         const float* __restrict__ Hs,
+                                                         const float* __restrict__ gs,
+                                                         const int* __restrict__ ii_opt,
+                                                         const int* __restrict__ jj_opt, int E, int N,
+                                                         int np, int ld, double* __restrict__ Haug) {
   if (st->done) return;
-  const int br = blockIdx.x;  // block row in [0, N]  (N = the b row, N+1.. = padding rows)
+  const int br = blockIdx.x;  // block row in [0, N); N = identity padding rows
+  const int lane = threadIdx.x;
   const int n = N * 7;
-  if (br == N + 1) {  // identity padding rows n..np-1
-    for (int r = n; r < np; r++)
-      for (int cidx = threadIdx.x; cidx < ld; cidx += 256) Haug[(size_t)r * ld + cidx] = (cidx == r) ? 1.0 : 0.0;
+  if (br == N) {
+    for (int r = n + lane; r < np; r += 64) Haug[(size_t)r * ld + r] = 1.0;
     return;
   }
-  extern __shared__ double rowbuf[];  // 7 x ld
-  const int rows = (br == N) ? 1 : 7;
-  for (int k = threadIdx.x; k < rows * ld; k += 256) rowbuf[k] = 0.0;
-  __syncthreads();
-  if (br < N) {
-    // lhs: blocks [ii,ii], [ii,jj], [jj,ii], [jj,jj]  (update_lhs, gn_kernels.cu:1201-1203)
-    for (int blk = 0; blk < 4; blk++) {
-      const int* rix = (blk < 2) ? ii_opt : jj_opt;
-      const int* cix = (blk & 1) ? jj_opt : ii_opt;
-      for (int e = 0; e < E; e++) {
-        if (rix[e] != br) continue;  // wave-uniform
-        const int cj = cix[e];
-        if (cj < 0) continue;
-        if (threadIdx.x < 49) {
-          const int k = threadIdx.x / 7, l = threadIdx.x % 7;
-          rowbuf[k * ld + 7 * cj + l] += (double)Hs[((size_t)blk * E + e) * 49 + threadIdx.x];
+  __shared__ double tab[kTab][49];
+  __shared__ int tabcol[kTab];
+  int ntab = 0;
+  double bacc = 0.0;  // lanes 0..6: rhs block of this pose
+  const int k7 = lane / 7, l7 = lane % 7;
+  for (int blk = 0; blk < 4; blk++) {
+    const int* rix = (blk < 2) ? ii_opt : jj_opt;
+    const int* cix = (blk & 1) ? jj_opt : ii_opt;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+      const int e = e0 + lane;
+      const bool row_match = e < E && rix[e] == br;
+      const int cj_l = row_match ? cix[e] : -1;
+      unsigned long long m = __ballot(row_match);
+      while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int ee = e0 + b;
+        if ((blk == 0 || blk == 2) && lane < 7)  // rhs: gs[0] rows of ii == br, then gs[1] rows of jj == br
+          bacc += (double)gs[((size_t)(blk >> 1) * E + ee) * 7 + lane];
+        const int cj = __shfl(cj_l, b, 64);
+        if (cj < 0) continue;  // pinned column
+        const double v = lane < 49 ? (double)Hs[((size_t)blk * E + ee) * 49 + lane] : 0.0;
+        const unsigned long long hit = __ballot(lane < ntab && tabcol[lane] == cj);
+        int slot = hit ? __ffsll((long long)hit) - 1 : -1;
+        if (slot < 0 && ntab < kTab) {
+          slot = ntab++;
+          if (lane == 0) tabcol[slot] = cj;
+          if (lane < 49) tab[slot][lane] = 0.0;
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (lane < 49) {
+          if (slot >= 0) tab[slot][lane] += v;
+          else Haug[(size_t)(7 * br + k7) * ld + 7 * cj + l7] += v;
         }
       }
     }
-    __syncthreads();
-    for (int k = threadIdx.x; k < 7 * ld; k += 256) Haug[(size_t)(7 * br + k / ld) * ld + (k % ld)] = rowbuf[k];
-  } else {
-    // rhs row (update_rhs, gn_kernels.cu:1205-1206): b[i] += gs[0][e] (i = ii), gs[1][e] (i = jj)
-    if (threadIdx.x < 7) {
-      for (int blk = 0; blk < 2; blk++) {
-        const int* rix = blk ? jj_opt : ii_opt;
-        for (int e = 0; e < E; e++) {
-          const int i = rix[e];
-          if (i >= 0) rowbuf[7 * i + threadIdx.x] += (double)gs[((size_t)blk * E + e) * 7 + threadIdx.x];
-        }
-      }
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < ld; k += 256) Haug[(size_t)np * ld + k] = rowbuf[k];
   }
+  __syncthreads();
+  for (int s = 0; s < ntab; s++) {
+    const int cj = tabcol[s];
+    if (lane < 49) Haug[(size_t)(7 * br + k7) * ld + 7 * cj + l7] += tab[s][lane];
+  }
+  if (lane < 7) Haug[(size_t)np * ld + 7 * br + lane] = bacc;
 }
 
-// panel step: factor the kNB x kNB diagonal block at j0 in LDS, then solve the rows below it
-// (including the augmented b row): L21 = A21 L11^-T.
-__global__ __launch_bounds__(256) void chol_panel_kernel(GnState* __restrict__ st, double* __restrict__ A,
-                                                         int np, int ld, int j0) {
+// ---------------------------------------------------------------------------------------------
+// blocked right-looking LL^T, one launch per panel
+// ---------------------------------------------------------------------------------------------
+// chol_step<NB>(j0): panel j0 (columns j0..j0+NB, rows below its diagonal block) is final.  Every 64x64
+// tile of the lower triangle of the trailing matrix (rows j1..np INCLUDING the rhs row np, columns
+// j1..np-1, j1 = j0 + NB) gets the rank-NB update A -= L_i L_j^T on the f64 matrix cores.  The tiles of
+// the first tile column additionally finish the NEXT panel (columns j1..j1+NB): each of them computes
+// the updated diagonal block D = A11 - Lp Lp^T itself (same code in every workgroup: identical bits),
+// factors it in LDS and solves its own rows X L11^T = A21'.  Nobody writes A11 in this launch (the other
+// workgroups read it): the factor of the diagonal block goes to the side array Ldiag[panel].
+// j0 = -NB is the prologue: no update, only the first panel is finished.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+template <int NB>
+__global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st, double* __restrict__ A,
+                                                        double* __restrict__ Ldiag, int np, int ld, int j0) {
   if (st->done) return;
-  __shared__ double L[kNB][kNB + 1];
+  constexpr int LS = NB + 2;   // LDS row stride of the panel rows: conflict-free f64 MFMA operand reads
+  constexpr int TS = kTile + 1;
+  constexpr int DS = NB + 1;
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (tj > ti) return;
+  const int j1 = j0 + NB;
+  const int r0 = j1 + ti * kTile, c0 = j1 + tj * kTile;
+  if (r0 > np || c0 >= np) return;
+  const bool has_update = j0 >= 0;
+  extern __shared__ double sh[];
+  double* Li = sh;                        // [64][LS]
+  double* Lj = sh + kTile * LS;           // [64][LS]
+  double* T = sh;                         // [64][TS] aliases Li/Lj after the MFMA loop (first tile column)
+  double* D = sh + 2 * kTile * LS;        // [NB][DS]
   __shared__ int fail;
   const int t = threadIdx.x;
-  if (t == 0) fail = 0;
-  for (int k = t; k < kNB * kNB; k += 256) {
-    const int r = k / kNB, c = k % kNB;
-    L[r][c] = (c <= r) ? A[(size_t)(j0 + r) * ld + j0 + c] : 0.0;
-  }
-  __syncthreads();
-  for (int j = 0; j < kNB; j++) {
-    if (t == 0) {
-      const double d = L[j][j];
-      if (!(d > 0.0)) { fail = 1; L[j][j] = 1.0; }
-      else L[j][j] = sqrt(d);
-    }
-    __syncthreads();
-    const double dj = L[j][j];
-    if (t > j && t < kNB) L[t][j] /= dj;
-    __syncthreads();
-    // rank-1 update of the trailing lower triangle
-    for (int k = t; k < (kNB - j - 1) * (kNB - j - 1); k += 256) {
-      const int r = j + 1 + k / (kNB - j - 1), c = j + 1 + k % (kNB - j - 1);
-      if (c <= r) L[r][c] -= L[r][j] * L[c][j];
-    }
-    __syncthreads();
-  }
-  if (fail && t == 0) st->chol_fail = 1;
-  for (int k = t; k < kNB * kNB; k += 256) {
-    const int r = k / kNB, c = k % kNB;
-    if (c <= r) A[(size_t)(j0 + r) * ld + j0 + c] = L[r][c];
-  }
-  // rows below: x L11^T = a  -> forward substitution over columns, one row per thread
-  for (int r = j0 + kNB + t; r <= np; r += 256) {
-    double x[kNB];
-    double* row = A + (size_t)r * ld + j0;
-#pragma unroll
-    for (int c = 0; c < kNB; c++) x[c] = row[c];
-#pragma unroll
-    for (int c = 0; c < kNB; c++) {
-      double s = x[c];
-#pragma unroll
-      for (int k = 0; k < c; k++) s -= x[k] * L[c][k];
-      x[c] = s / L[c][c];
-    }
-#pragma unroll
-    for (int c = 0; c < kNB; c++) row[c] = x[c];
-  }
-}
+  const int lane = t & 63, wid = t >> 6;
 
-// trailing update: C[i][j] -= sum_k L[i][j0+k] L[j][j0+k] on 64x64 tiles of the lower triangle
-// (rows up to and including the b row np).
-__global__ __launch_bounds__(256) void chol_update_kernel(const GnState* __restrict__ st,
-                                                          double* __restrict__ A, int np, int ld, int j0) {
-  if (st->done) return;
-  const int base = j0 + kNB;
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if (tj > ti) return;
-  const int r0 = base + ti * 64, c0 = base + tj * 64;
-  if (r0 > np || c0 >= np) return;
-  __shared__ double Li[kNB][65];
-  __shared__ double Lj[kNB][65];
-  const int t = threadIdx.x;
-  for (int k = t; k < 64 * kNB; k += 256) {
-    const int r = k / kNB, c = k % kNB;
-    Li[c][r] = (r0 + r <= np) ? A[(size_t)(r0 + r) * ld + j0 + c] : 0.0;
-    Lj[c][r] = (c0 + r < np) ? A[(size_t)(c0 + r) * ld + j0 + c] : 0.0;
-  }
-  __syncthreads();
-  const int tx = t & 15, ty = t >> 4;
-  double acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+  // ---- first tile column: D = A11 - Lp Lp^T (before the panel rows overwrite the scratch) ----
+  if (tj == 0) {
+    double* Lp = sh;  // [NB][LS]
+    for (int k = t; k < NB * NB; k += 256) {
+      const int a = k / NB, b = k % NB;
+      D[a * DS + b] = A[(size_t)(j1 + a) * ld + j1 + b];
+      Lp[a * LS + b] = has_update ? A[(size_t)(j1 + a) * ld + j0 + b] : 0.0;
+    }
+    if (t == 0) fail = 0;
+    __syncthreads();
+    if (has_update) {
+      for (int k = t; k < NB * NB; k += 256) {
+        const int a = k / NB, b = k % NB;
+        if (b <= a) {
+          double s = 0.0;
 #pragma unroll 8
-  for (int k = 0; k < kNB; k++) {
-    double li[4], lj[4];
-#pragma unroll
-    for (int a = 0; a < 4; a++) { li[a] = Li[k][ty * 4 + a]; lj[a] = Lj[k][tx * 4 + a]; }
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) acc[a][b] = fma(li[a], lj[b], acc[a][b]);
+          for (int q = 0; q < NB; q++) s = fma(Lp[a * LS + q], Lp[b * LS + q], s);
+          D[a * DS + b] -= s;
+        }
+      }
+    }
+    __syncthreads();
   }
+
+  // ---- rank-NB update of this tile on the matrix cores ----
+  f64x4 acc[2][2];
 #pragma unroll
-  for (int a = 0; a < 4; a++) {
-    const int r = r0 + ty * 4 + a;
-    if (r > np) continue;
+  for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const int c = c0 + tx * 4 + b;
-      if (c < np && c <= r) A[(size_t)r * ld + c] -= acc[a][b];
+    for (int b = 0; b < 2; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int wr = wid >> 1, wc = wid & 1;
+  if (has_update) {
+    for (int k = t; k < kTile * NB; k += 256) {
+      const int r = k / NB, q = k % NB;
+      Li[r * LS + q] = (r0 + r <= np) ? A[(size_t)(r0 + r) * ld + j0 + q] : 0.0;
+      Lj[r * LS + q] = (c0 + r < np) ? A[(size_t)(c0 + r) * ld + j0 + q] : 0.0;
+    }
+    __syncthreads();
+    const int fi = lane & 15, fk = lane >> 4;
+#pragma unroll 4
+    for (int k4 = 0; k4 < NB; k4 += 4) {
+      double a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        a[m] = Li[(32 * wr + 16 * m + fi) * LS + k4 + fk];
+        b[m] = Lj[(32 * wc + 16 * m + fi) * LS + k4 + fk];
+      }
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();  // all fragment reads done: T may alias Li/Lj
+  }
+
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const int fcol = lane & 15, frow = lane >> 4;
+  if (tj != 0) {
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int r = r0 + 32 * wr + 16 * m + frow + 4 * g;
+          const int c = c0 + 32 * wc + 16 * n + fcol;
+          if (r <= np && c < np && c <= r) A[(size_t)r * ld + c] -= acc[m][n][g];
+        }
+    return;
+  }
+
+  // ---- first tile column: updated values into T; columns beyond the panel go straight back ----
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int rr = 32 * wr + 16 * m + frow + 4 * g;
+        const int cc = 32 * wc + 16 * n + fcol;
+        const int r = r0 + rr, c = c0 + cc;
+        double v = 0.0;
+        if (r <= np && c < np && c <= r) v = A[(size_t)r * ld + c] - acc[m][n][g];
+        if (cc < NB) T[rr * TS + cc] = v;
+        else if (r <= np && c < np && c <= r) A[(size_t)r * ld + c] = v;
+      }
+
+  // ---- factor D in LDS (every workgroup of the column: same bits) ----
+  for (int j = 0; j < NB; j++) {
+    __syncthreads();
+    if (t == 0) {
+      const double d = D[j * DS + j];
+      if (!(d > 0.0)) { fail = 1; D[j * DS + j] = 1.0; }
+      else D[j * DS + j] = sqrt(d);
+    }
+    __syncthreads();
+    const double dj = D[j * DS + j];
+    if (t > j && t < NB) D[t * DS + j] /= dj;
+    __syncthreads();
+    const int rem = NB - j - 1;
+    for (int k = t; k < rem * rem; k += 256) {
+      const int r = j + 1 + k / rem, c = j + 1 + k % rem;
+      if (c <= r) D[r * DS + c] -= D[r * DS + j] * D[c * DS + j];
+    }
+  }
+  __syncthreads();
+  if (ti == 0) {
+    if (fail && t == 0) st->chol_fail = 1;
+    double* Ld = Ldiag + (size_t)(j1 / NB) * NB * NB;
+    for (int k = t; k < NB * NB; k += 256) {
+      const int a = k / NB, b = k % NB;
+      Ld[k] = (b <= a) ? D[a * DS + b] : 0.0;
+    }
+  }
+
+  // ---- rows of the panel below its diagonal block: x L11^T = t, one row per lane of wave 0 ----
+  if (t < kTile) {
+    const int r = r0 + t;
+    const bool in_diag = (ti == 0) && (t < NB);
+    if (r <= np && !in_diag) {
+      double x[NB];
+#pragma unroll
+      for (int c = 0; c < NB; c++) x[c] = T[t * TS + c];
+#pragma unroll
+      for (int c = 0; c < NB; c++) {
+        double s = x[c];
+#pragma unroll
+        for (int k = 0; k < c; k++) s -= x[k] * D[c * DS + k];
+        x[c] = s / D[c * DS + c];
+      }
+      double* row = A + (size_t)r * ld + j1;
+#pragma unroll
+      for (int c = 0; c < NB; c++) row[c] = x[c];
     }
   }
 }
 
-// back substitution L^T x = y (y = row np), dx = -x, retraction, convergence flag.
-__global__ __launch_bounds__(256) void chol_backsolve_retract_kernel(GnState* __restrict__ st,
-                                                                     double* __restrict__ A, int np,
-                                                                     int ld, int N, int num_fix,
-                                                                     float* __restrict__ Twc,
-                                                                     float* __restrict__ dx,
-                                                                     float delta_thresh) {
+// back substitution L^T x = y (y = row np), one launch per panel from the last to the first: every
+// workgroup solves the panel's NB unknowns itself (column-oriented, one wave) and then removes them
+// from its 256 entries of y above the panel.  x goes to xs (np doubles).
+template <int NB>
+__global__ __launch_bounds__(256) void chol_back_kernel(const GnState* __restrict__ st,
+                                                        double* __restrict__ A,
+                                                        const double* __restrict__ Ldiag,
+                                                        double* __restrict__ xs, int np, int ld, int jb) {
+  if (st->done) return;
+  __shared__ double Lb[NB][NB + 1];
+  __shared__ double xb[NB];
+  const int t = threadIdx.x;
+  double* y = A + (size_t)np * ld;
+  const double* Ld = Ldiag + (size_t)(jb / NB) * NB * NB;
+  for (int k = t; k < NB * NB; k += 256) Lb[k / NB][k % NB] = Ld[k];
+  __syncthreads();
+  if (t < 64) {
+    double s = t < NB ? y[jb + t] : 0.0;
+    for (int c = NB - 1; c >= 0; c--) {
+      double xc = 0.0;
+      if (t == c) xc = s / Lb[c][c];
+      xc = __shfl(xc, c, 64);
+      if (t == c) xb[c] = xc;
+      if (t < c) s -= Lb[c][t] * xc;
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && t < NB) xs[jb + t] = xb[t];
+  const int i = blockIdx.x * 256 + t;
+  if (i < jb) {
+    double s = y[i];
+#pragma unroll 8
+    for (int k = 0; k < NB; k++) s -= A[(size_t)(jb + k) * ld + i] * xb[k];  // rows of L: contiguous in i
+    y[i] = s;
+  }
+}
+
+// dx = -x, retraction, convergence flag
+__global__ __launch_bounds__(256) void gn_finish_kernel(GnState* __restrict__ st,
+                                                        const double* __restrict__ xs, int N, int num_fix,
+                                                        float* __restrict__ Twc, float* __restrict__ dx,
+                                                        float delta_thresh) {
   if (st->done) return;
   const int t = threadIdx.x;
   const int n = N * 7;
-  double* y = A + (size_t)np * ld;
-  __shared__ double xb[kNB];
-  __shared__ double Lb[kNB][kNB + 1];
   __shared__ float red[256];
   const bool fail = st->chol_fail != 0;
-  if (!fail) {
-    for (int j0 = np - kNB; j0 >= 0; j0 -= kNB) {
-      for (int k = t; k < kNB * kNB; k += 256) Lb[k / kNB][k % kNB] = A[(size_t)(j0 + k / kNB) * ld + j0 + k % kNB];
-      __syncthreads();
-      if (t == 0) {
-        for (int c = kNB - 1; c >= 0; c--) {
-          double s = y[j0 + c];
-          for (int k = c + 1; k < kNB; k++) s -= Lb[k][c] * xb[k];
-          xb[c] = s / Lb[c][c];
-        }
-        for (int c = 0; c < kNB; c++) y[j0 + c] = xb[c];
-      }
-      __syncthreads();
-      // y[i] -= sum_k L[j0+k][i] x[k]  for i < j0   (rows of L are contiguous in i: coalesced)
-      for (int i = t; i < j0; i += 256) {
-        double s = y[i];
-#pragma unroll 8
-        for (int k = 0; k < kNB; k++) s -= A[(size_t)(j0 + k) * ld + i] * xb[k];
-        y[i] = s;
-      }
-      __syncthreads();
-    }
-  }
   float ss = 0.0f;
   for (int k = t; k < n; k += 256) {
-    const float d = fail ? 0.0f : -(float)y[k];  // "NOTE: Accounting for negative here!" :1208-1209
+    const float d = fail ? 0.0f : -(float)xs[k];  // "NOTE: Accounting for negative here!" :1208-1209
     dx[k] = d;
     ss = fmaf(d, d, ss);
   }
@@ -585,22 +755,29 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 struct GnWorkspace {
   GnState* st;
-  int *ii_edge, *jj_edge, *ii_opt, *jj_opt, *first, *num_unique;
+  int *ii_edge, *jj_edge, *ii_opt, *jj_opt, *first;
   float* econst;
-  float* partial;
   float* Hs;
   float* gs;
   double* Haug;
-  int S, chunk_len, np, ld;
-  size_t bytes;
+  double* Ldiag;
+  double* xs;
+  int* counts;
+  float* partial;
+  float* stream;
+  int S, chunk_len, np, ld, nb;
+  size_t bytes_fixed;  // everything the index / solve entry points touch
+  size_t bytes;        // + compact stream, counts and partials of `local_edges` edges
 };
 
-static GnWorkspace gn_carve(void* base, int P, int E, int HW) {
+// Layout: arrays whose size depends only on (P, E) first, the per-local-edge arrays last.
+static GnWorkspace gn_carve(void* base, int P, int E, int HW, int local_edges) {
   GnWorkspace w;
   const int N = P > 1 ? P - 1 : 0;
   const int n = N * 7;
-  w.np = (int)align_up((size_t)(n > 0 ? n : 1), kNB);
+  w.np = (int)align_up((size_t)(n > 0 ? n : 1), kTile);
   w.ld = w.np;
+  w.nb = n > 2048 ? 64 : 32;
   // split every edge over S workgroups: >= ~1k workgroups per launch, >= 16 points per thread
   int S = E > 0 ? (1024 + E - 1) / E : 1;
   const int s_cap = HW / (256 * 16) > 0 ? HW / (256 * 16) : 1;
@@ -617,23 +794,27 @@ static GnWorkspace gn_carve(void* base, int P, int E, int HW) {
   w.ii_opt = (int*)take(sizeof(int) * (size_t)E);
   w.jj_opt = (int*)take(sizeof(int) * (size_t)E);
   w.first = (int*)take(sizeof(int) * 2 * (size_t)E);
-  w.num_unique = (int*)take(sizeof(int));
   w.econst = (float*)take(sizeof(float) * (size_t)E * kEdgeConst);
-  w.partial = (float*)take(sizeof(float) * (size_t)E * S * kAcc);
   w.Hs = (float*)take(sizeof(float) * (size_t)4 * E * 49);
   w.gs = (float*)take(sizeof(float) * (size_t)2 * E * 7);
   w.Haug = (double*)take(sizeof(double) * (size_t)(w.np + 1) * w.ld);
+  w.Ldiag = (double*)take(sizeof(double) * (size_t)w.np * w.nb);
+  w.xs = (double*)take(sizeof(double) * (size_t)w.np);
+  w.bytes_fixed = off;
+  const size_t L = local_edges > 0 ? (size_t)local_edges : 0;
+  w.counts = (int*)take(sizeof(int) * L * S);
+  w.partial = (float*)take(sizeof(float) * L * S * kAcc);
+  w.stream = (float*)take(sizeof(float) * L * S * (size_t)w.chunk_len * kPlanes);
   w.bytes = off;
   return w;
 }
 
-static void fill_params(GnParams& P, int kind, const float* K_dev, float sigma_a, float sigma_b,
-                        float C_thresh, float Q_thresh, int height, int width, int pixel_border,
-                        float z_eps) {
+static void fill_params(GnParams& P, int kind, const float* K_dev, float sigma_a, float sigma_b, int height,
+                        int width, int pixel_border, float z_eps) {
   P.sa_inv = 1.0f / sigma_a;
   P.sb_inv = kind == 2 ? 0.0f : 1.0f / sigma_b;
-  P.C_thresh = C_thresh;
-  P.Q_thresh = Q_thresh;
+  P.C_thresh = 0.0f;
+  P.Q_thresh = 0.0f;
   P.height = height;
   P.width = width > 0 ? width : 1;
   P.border_lo = (float)pixel_border;
@@ -643,58 +824,70 @@ static void fill_params(GnParams& P, int kind, const float* K_dev, float sigma_a
   P.K = K_dev;
 }
 
-// edges [e0, e0+cnt) of the global edge list; idx/vm/Q are LOCAL arrays of cnt rows; Hs/gs are the
-// global [4,E,7,7] / [2,E,7] buffers.
-static int launch_accumulate(int kind, const GnWorkspace& w, const float* Twc, const float* Xs,
-                             const float* Cs, const int64_t* idx, const uint8_t* vm, const float* Q, int HW,
-                             int E, int e0, int cnt, const GnParams& P, float* Hs, float* gs, hipStream_t s) {
+// edges [e0, e0+cnt) of the global edge list; the stream / counts / partials are indexed by the LOCAL
+// edge (0..cnt-1); Hs/gs are the global [4,E,7,7] / [2,E,7] buffers.
+static int launch_accumulate(int kind, const GnWorkspace& w, const float* Twc, int E, int e0, int cnt,
+                             const GnParams& P, float* Hs, float* gs, hipStream_t s) {
   if (cnt <= 0) return MSLAM_OK;
   hipLaunchKernelGGL(gn_edge_setup_kernel, dim3((cnt + 63) / 64), dim3(64), 0, s, w.st, Twc, w.ii_edge + e0,
                      w.jj_edge + e0, cnt, w.econst);
   dim3 grid(w.S, cnt);
   if (kind == 0)
-    hipLaunchKernelGGL(gn_accum_kernel<0>, grid, dim3(256), 0, s, w.st, w.econst, Xs, Cs, w.ii_edge + e0,
-                       w.jj_edge + e0, idx, vm, Q, HW, w.chunk_len, P, w.partial);
+    hipLaunchKernelGGL(gn_accum_kernel<0>, grid, dim3(256), 0, s, w.st, w.econst, w.stream, w.counts, w.chunk_len,
+                       P, w.partial);
   else if (kind == 1)
-    hipLaunchKernelGGL(gn_accum_kernel<1>, grid, dim3(256), 0, s, w.st, w.econst, Xs, Cs, w.ii_edge + e0,
-                       w.jj_edge + e0, idx, vm, Q, HW, w.chunk_len, P, w.partial);
+    hipLaunchKernelGGL(gn_accum_kernel<1>, grid, dim3(256), 0, s, w.st, w.econst, w.stream, w.counts, w.chunk_len,
+                       P, w.partial);
   else
-    hipLaunchKernelGGL(gn_accum_kernel<2>, grid, dim3(256), 0, s, w.st, w.econst, Xs, Cs, w.ii_edge + e0,
-                       w.jj_edge + e0, idx, vm, Q, HW, w.chunk_len, P, w.partial);
+    hipLaunchKernelGGL(gn_accum_kernel<2>, grid, dim3(256), 0, s, w.st, w.econst, w.stream, w.counts, w.chunk_len,
+                       P, w.partial);
   hipLaunchKernelGGL(gn_reduce_kernel, dim3(cnt), dim3(64), 0, s, w.st, w.partial, w.S, Twc, w.ii_edge + e0, e0, E,
                      Hs, gs);
   return check_hip(hipGetLastError(), "gn accumulate launch");
 }
 
+template <int NB>
+static int launch_cholesky(const GnWorkspace& w, hipStream_t s) {
+  constexpr size_t shmem = sizeof(double) * (2 * kTile * (NB + 2) + NB * (NB + 1));
+  static bool attr_set = false;
+  if (shmem > 48 * 1024 && !attr_set) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)chol_step_kernel<NB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
+                       "hipFuncSetAttribute(chol_step)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  for (int j0 = -NB; j0 + NB < w.np; j0 += NB) {
+    const int j1 = j0 + NB;
+    const int tiles_r = (w.np - j1 + 1 + kTile - 1) / kTile;           // rows j1..np (np = the rhs row)
+    const int tiles_c = j0 < 0 ? 1 : (w.np - j1 + kTile - 1) / kTile;  // prologue: only the panel column
+    hipLaunchKernelGGL(chol_step_kernel<NB>, dim3(tiles_c, tiles_r), dim3(256), shmem, s, w.st, w.Haug, w.Ldiag,
+                       w.np, w.ld, j0);
+  }
+  for (int jb = w.np - NB; jb >= 0; jb -= NB) {
+    const int blocks = jb > 0 ? (jb + 255) / 256 : 1;
+    hipLaunchKernelGGL(chol_back_kernel<NB>, dim3(blocks), dim3(256), 0, s, w.st, w.Haug, w.Ldiag, w.xs, w.np,
+                       w.ld, jb);
+  }
+  return MSLAM_OK;
+}
+
 static int launch_solve(const GnWorkspace& w, const float* Hs, const float* gs, int E, int P, float* Twc,
                         float* dx, float delta_thresh, hipStream_t s) {
   const int N = P - 1;
-  const size_t shmem = sizeof(double) * 7 * (size_t)w.ld;
-  MSLAM_REQUIRE(shmem <= 160 * 1024, "gauss_newton: %d poses exceed the assemble kernel's LDS row buffer", P);
-  if (shmem > 64 * 1024) {
-    int rc = check_hip(hipFuncSetAttribute((const void*)gn_assemble_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem),
-                       "hipFuncSetAttribute");
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(gn_assemble_kernel, dim3(N + 2), dim3(256), shmem, s, w.st, Hs, gs, w.ii_opt, w.jj_opt, E, N,
-                     w.np, w.ld, w.Haug);
-  for (int j0 = 0; j0 < w.np; j0 += kNB) {
-    hipLaunchKernelGGL(chol_panel_kernel, dim3(1), dim3(256), 0, s, w.st, w.Haug, w.np, w.ld, j0);
-    const int rem = w.np + 1 - (j0 + kNB);  // rows below the panel, including the b row
-    if (rem > 0) {
-      const int tiles = (rem + 63) / 64;
-      hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(256), 0, s, w.st, w.Haug, w.np, w.ld, j0);
-    }
-  }
-  hipLaunchKernelGGL(chol_backsolve_retract_kernel, dim3(1), dim3(256), 0, s, w.st, w.Haug, w.np, w.ld, N, 1, Twc,
-                     dx, delta_thresh);
+  int rc = check_hip(hipMemsetAsync(w.Haug, 0, sizeof(double) * (size_t)(w.np + 1) * w.ld, s), "Haug memset");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_assemble_kernel, dim3(N + 1), dim3(64), 0, s, w.st, Hs, gs, w.ii_opt, w.jj_opt, E, N, w.np,
+                     w.ld, w.Haug);
+  rc = w.nb == 64 ? launch_cholesky<64>(w, s) : launch_cholesky<32>(w, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_finish_kernel, dim3(1), dim3(256), 0, s, w.st, w.xs, N, 1, Twc, dx, delta_thresh);
   return check_hip(hipGetLastError(), "gn solve launch");
 }
 
-static int gn_check_ws(const GnWorkspace& w, void* workspace, size_t workspace_bytes, const char* who) {
-  if (!workspace || w.bytes > workspace_bytes) {
-    set_error("%s: workspace too small (%zu < %zu)", who, workspace ? workspace_bytes : (size_t)0, w.bytes);
+static int gn_check_ws(size_t need, void* workspace, size_t workspace_bytes, const char* who) {
+  if (!workspace || need > workspace_bytes) {
+    set_error("%s: workspace too small (%zu < %zu)", who, workspace ? workspace_bytes : (size_t)0, need);
     return MSLAM_ENOMEM;
   }
   return MSLAM_OK;
@@ -704,9 +897,9 @@ static int gn_check_ws(const GnWorkspace& w, void* workspace, size_t workspace_b
 
 using namespace mslam;
 
-extern "C" size_t mslam_gn_workspace_bytes(int num_poses, int num_edges, int num_points) {
-  if (num_poses < 0 || num_edges < 0 || num_points < 0) return 0;
-  return gn_carve(nullptr, num_poses, num_edges, num_points).bytes;
+extern "C" size_t mslam_gn_workspace_bytes(int num_poses, int num_edges, int num_points, int local_edges) {
+  if (num_poses < 0 || num_edges < 0 || num_points < 0 || local_edges < 0) return 0;
+  return gn_carve(nullptr, num_poses, num_edges, num_points, local_edges).bytes;
 }
 
 extern "C" int mslam_gn_begin(const int64_t* ii, const int64_t* jj, int num_poses, int num_edges,
@@ -714,37 +907,53 @@ extern "C" int mslam_gn_begin(const int64_t* ii, const int64_t* jj, int num_pose
   MSLAM_REQUIRE(num_poses >= 2 && num_edges >= 1, "gn_begin: need >= 2 poses and >= 1 edge");
   MSLAM_REQUIRE(ii && jj, "gn_begin: null pointer");
   MSLAM_REQUIRE(num_edges <= 65535, "gn_begin: %d edges exceed the grid limit", num_edges);
-  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points);
-  int rc = gn_check_ws(w, workspace, workspace_bytes, "gn_begin");
+  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, 0);
+  int rc = gn_check_ws(w.bytes_fixed, workspace, workspace_bytes, "gn_begin");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  const int blocks = (2 * num_edges + 255) / 256;
   hipLaunchKernelGGL(gn_state_init_kernel, dim3(1), dim3(1), 0, s, w.st);
-  hipLaunchKernelGGL(gn_index_kernel, dim3(1), dim3(256), 0, s, ii, jj, num_edges, 1, w.ii_edge, w.jj_edge,
-                     w.ii_opt, w.jj_opt, w.first, w.num_unique);
+  hipLaunchKernelGGL(gn_first_kernel, dim3(blocks), dim3(256), 0, s, ii, jj, num_edges, w.first);
+  hipLaunchKernelGGL(gn_rank_kernel, dim3(blocks), dim3(256), 0, s, ii, jj, num_edges, 1, w.first, w.ii_edge,
+                     w.jj_edge, w.ii_opt, w.jj_opt);
   return check_hip(hipGetLastError(), "gn_begin launch");
 }
 
-extern "C" int mslam_gn_accumulate(int kind, const float* Twc, const float* Xs, const float* Cs, const float* K,
-                                   const int64_t* idx_ii2jj, const uint8_t* valid_match, const float* Q,
-                                   int num_poses, int num_points, int num_edges, int edge_begin,
-                                   int edge_count, float sigma_a, float sigma_b, float C_thresh,
-                                   float Q_thresh, int height, int width, int pixel_border, float z_eps,
-                                   float* Hs, float* gs, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
+extern "C" int mslam_gn_compact(const float* Xs, const float* Cs, const int64_t* idx_ii2jj,
+                                const uint8_t* valid_match, const float* Q, int num_poses, int num_points,
+                                int num_edges, int edge_begin, int edge_count, float C_thresh, float Q_thresh,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  MSLAM_REQUIRE(num_poses >= 2 && num_points >= 1 && num_edges >= 1, "gn_compact: bad sizes");
+  MSLAM_REQUIRE(edge_begin >= 0 && edge_count >= 0 && edge_begin + edge_count <= num_edges,
+                "gn_compact: edge range [%d,%d) outside [0,%d)", edge_begin, edge_begin + edge_count, num_edges);
+  if (edge_count == 0) return MSLAM_OK;
+  MSLAM_REQUIRE(Xs && Cs && idx_ii2jj && valid_match && Q, "gn_compact: null pointer");
+  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, edge_count);
+  int rc = gn_check_ws(w.bytes, workspace, workspace_bytes, "gn_compact");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_compact_kernel, dim3(w.S, edge_count), dim3(256), 0, (hipStream_t)stream, Xs, Cs,
+                     w.ii_edge + edge_begin, w.jj_edge + edge_begin, idx_ii2jj, valid_match, Q, num_points,
+                     w.chunk_len, C_thresh, Q_thresh, w.stream, w.counts);
+  return check_hip(hipGetLastError(), "gn_compact launch");
+}
+
+extern "C" int mslam_gn_accumulate(int kind, const float* Twc, const float* K, int num_poses, int num_points,
+                                   int num_edges, int edge_begin, int edge_count, float sigma_a, float sigma_b,
+                                   int height, int width, int pixel_border, float z_eps, float* Hs, float* gs,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
   MSLAM_REQUIRE(kind >= 0 && kind <= 2, "gn_accumulate: kind must be 0 (rays), 1 (calib) or 2 (points)");
   MSLAM_REQUIRE(num_poses >= 2 && num_points >= 1 && num_edges >= 1, "gn_accumulate: bad sizes");
   MSLAM_REQUIRE(edge_begin >= 0 && edge_count >= 0 && edge_begin + edge_count <= num_edges,
                 "gn_accumulate: edge range [%d,%d) outside [0,%d)", edge_begin, edge_begin + edge_count, num_edges);
   if (edge_count == 0) return MSLAM_OK;
-  MSLAM_REQUIRE(Twc && Xs && Cs && idx_ii2jj && valid_match && Q && Hs && gs, "gn_accumulate: null pointer");
+  MSLAM_REQUIRE(Twc && Hs && gs, "gn_accumulate: null pointer");
   MSLAM_REQUIRE(kind != 1 || (K && width > 0 && height > 0), "gn_accumulate: calib needs K, height, width");
-  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points);
-  int rc = gn_check_ws(w, workspace, workspace_bytes, "gn_accumulate");
+  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, edge_count);
+  int rc = gn_check_ws(w.bytes, workspace, workspace_bytes, "gn_accumulate");
   if (rc) return rc;
   GnParams P;
-  fill_params(P, kind, K, sigma_a, sigma_b, C_thresh, Q_thresh, height, width, pixel_border, z_eps);
-  return launch_accumulate(kind, w, Twc, Xs, Cs, idx_ii2jj, valid_match, Q, num_points, num_edges, edge_begin,
-                           edge_count, P, Hs, gs, (hipStream_t)stream);
+  fill_params(P, kind, K, sigma_a, sigma_b, height, width, pixel_border, z_eps);
+  return launch_accumulate(kind, w, Twc, num_edges, edge_begin, edge_count, P, Hs, gs, (hipStream_t)stream);
 }
 
 extern "C" int mslam_gn_solve_retract(const float* Hs, const float* gs, int num_poses, int num_edges,
@@ -752,8 +961,8 @@ extern "C" int mslam_gn_solve_retract(const float* Hs, const float* gs, int num_
                                       void* workspace, size_t workspace_bytes, void* stream) {
   MSLAM_REQUIRE(num_poses >= 2 && num_edges >= 1, "gn_solve_retract: need >= 2 poses and >= 1 edge");
   MSLAM_REQUIRE(Hs && gs && Twc && dx, "gn_solve_retract: null pointer");
-  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points);
-  int rc = gn_check_ws(w, workspace, workspace_bytes, "gn_solve_retract");
+  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, 0);
+  int rc = gn_check_ws(w.bytes_fixed, workspace, workspace_bytes, "gn_solve_retract");
   if (rc) return rc;
   return launch_solve(w, Hs, gs, num_edges, num_poses, Twc, dx, delta_thresh, (hipStream_t)stream);
 }
@@ -761,8 +970,8 @@ extern "C" int mslam_gn_solve_retract(const float* Hs, const float* gs, int num_
 extern "C" int mslam_gn_status(int* status4, int num_poses, int num_edges, int num_points, void* workspace,
                                size_t workspace_bytes, void* stream) {
   MSLAM_REQUIRE(status4, "gn_status: null pointer");
-  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points);
-  int rc = gn_check_ws(w, workspace, workspace_bytes, "gn_status");
+  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, 0);
+  int rc = gn_check_ws(w.bytes_fixed, workspace, workspace_bytes, "gn_status");
   if (rc) return rc;
   return check_hip(hipMemcpyAsync(status4, w.st, sizeof(GnState), hipMemcpyDeviceToDevice, (hipStream_t)stream),
                    "gn_status copy");
@@ -781,15 +990,17 @@ static int gauss_newton_impl(int kind, float* Twc, const float* Xs, const float*
   MSLAM_REQUIRE(kind != 1 || (K && width > 0 && height > 0), "gauss_newton_calib needs K, height, width");
   int rc = mslam_gn_begin(ii, jj, num_poses, num_edges, num_points, workspace, workspace_bytes, stream);
   if (rc) return rc;
-  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points);
+  rc = mslam_gn_compact(Xs, Cs, idx_ii2jj, valid_match, Q, num_poses, num_points, num_edges, 0, num_edges, C_thresh,
+                        Q_thresh, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, num_edges);
   hipStream_t s = (hipStream_t)stream;
   GnParams P;
-  fill_params(P, kind, K, sigma_a, sigma_b, C_thresh, Q_thresh, height, width, pixel_border, z_eps);
+  fill_params(P, kind, K, sigma_a, sigma_b, height, width, pixel_border, z_eps);
   rc = check_hip(hipMemsetAsync(dx, 0, sizeof(float) * 7 * (size_t)(num_poses - 1), s), "dx memset");
   if (rc) return rc;
   for (int it = 0; it < max_iter; it++) {
-    rc = launch_accumulate(kind, w, Twc, Xs, Cs, idx_ii2jj, valid_match, Q, num_points, num_edges, 0, num_edges, P,
-                           w.Hs, w.gs, s);
+    rc = launch_accumulate(kind, w, Twc, num_edges, 0, num_edges, P, w.Hs, w.gs, s);
     if (rc) return rc;
     rc = launch_solve(w, w.Hs, w.gs, num_edges, num_poses, Twc, dx, delta_thresh, s);
     if (rc) return rc;

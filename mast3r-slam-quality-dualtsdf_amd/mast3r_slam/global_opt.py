@@ -156,7 +156,7 @@ def gauss_newton_sharded(kind, Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q
     e0, cnt = edge_slice(E, rank, world)
     dev = Twc.device
     L = _m.lib()
-    ws = mast3r_slam_backends._workspace(L.mslam_gn_workspace_bytes(P, E, HW), dev)
+    ws = mast3r_slam_backends._workspace(L.mslam_gn_workspace_bytes(P, E, HW, cnt), dev)
     blocks = torch.zeros(4 * E * 49 + 2 * E * 7, dtype=torch.float32, device=dev)  # one buffer, one all-reduce
     Hs, gs = blocks[: 4 * E * 49], blocks[4 * E * 49:]
     dx = torch.zeros((P - 1, 7), dtype=torch.float32, device=dev)
@@ -167,11 +167,14 @@ def gauss_newton_sharded(kind, Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q
     sa, sb = {"rays": (cfg["sigma_ray"], cfg["sigma_dist"]), "calib": (cfg["sigma_pixel"], cfg["sigma_depth"]),
               "points": (cfg.get("sigma_point", 0.05), 1.0)}[kind]
     _m.check(L.mslam_gn_begin(_m.ptr(ii), _m.ptr(jj), P, E, HW, _m.ptr(ws), ws.numel(), _m.stream_ptr()), "gn_begin")
+    # the pose-independent part (gather, confidence gates) once per call; the iterations stream the result
+    rc = L.mslam_gn_compact(_m.ptr(Xs), _m.ptr(Cs), _m.ptr(idx_l), _m.ptr(vm_l), _m.ptr(Q_l), P, HW, E, e0, cnt,
+                            float(cfg["C_conf"]), float(cfg["Q_conf"]), _m.ptr(ws), ws.numel(), _m.stream_ptr())
+    _m.check(rc, "gn_compact")
     for _ in range(int(cfg["max_iters"])):
         blocks.zero_()
         rc = L.mslam_gn_accumulate(
-            kid, _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(K) if K is not None else 0, _m.ptr(idx_l), _m.ptr(vm_l),
-            _m.ptr(Q_l), P, HW, E, e0, cnt, float(sa), float(sb), float(cfg["C_conf"]), float(cfg["Q_conf"]),
+            kid, _m.ptr(Twc), _m.ptr(K) if K is not None else 0, P, HW, E, e0, cnt, float(sa), float(sb),
             int(height), int(width), int(cfg["pixel_border"]), float(cfg["depth_eps"]), _m.ptr(Hs), _m.ptr(gs),
             _m.ptr(ws), ws.numel(), _m.stream_ptr())
         _m.check(rc, "gn_accumulate")

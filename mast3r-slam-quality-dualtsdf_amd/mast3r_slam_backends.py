@@ -88,7 +88,7 @@ def gauss_newton_rays(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_ray,
     """gn.cpp:28-52 / gn_kernels.cu:1140-1228.  Mutates Twc in place (rows >= 1); returns [dx]."""
     P, HW, E = _gn_common_checks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q)
     dx = torch.zeros((max(P - 1, 0), 7), dtype=torch.float32, device=Twc.device)
-    nbytes = _m.lib().mslam_gn_workspace_bytes(P, E, HW)
+    nbytes = _m.lib().mslam_gn_workspace_bytes(P, E, HW, E)
     ws = _workspace(nbytes, Twc.device)
     rc = _m.lib().mslam_gauss_newton_rays(
         _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(ii), _m.ptr(jj), _m.ptr(idx_ii2jj), _m.ptr(valid_match),
@@ -106,7 +106,7 @@ def gauss_newton_calib(Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, height
     _m.require_contiguous(K=K)
     _m.require_dtype(K, torch.float32, "K")
     dx = torch.zeros((max(P - 1, 0), 7), dtype=torch.float32, device=Twc.device)
-    nbytes = _m.lib().mslam_gn_workspace_bytes(P, E, HW)
+    nbytes = _m.lib().mslam_gn_workspace_bytes(P, E, HW, E)
     ws = _workspace(nbytes, Twc.device)
     rc = _m.lib().mslam_gauss_newton_calib(
         _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(K), _m.ptr(ii), _m.ptr(jj), _m.ptr(idx_ii2jj),
@@ -123,7 +123,7 @@ def gauss_newton_points(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, sigma_po
     """gn.cpp:3-26 / gn_kernels.cu:725-811 (exported by the reference, never called from its Python)."""
     P, HW, E = _gn_common_checks(Twc, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q)
     dx = torch.zeros((max(P - 1, 0), 7), dtype=torch.float32, device=Twc.device)
-    nbytes = _m.lib().mslam_gn_workspace_bytes(P, E, HW)
+    nbytes = _m.lib().mslam_gn_workspace_bytes(P, E, HW, E)
     ws = _workspace(nbytes, Twc.device)
     rc = _m.lib().mslam_gauss_newton_points(
         _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(ii), _m.ptr(jj), _m.ptr(idx_ii2jj), _m.ptr(valid_match),
@@ -149,13 +149,16 @@ def gn_blocks(kind, Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, sigma_a, 
     if Hs is None:
         Hs = torch.zeros((4, E, 7, 7), dtype=torch.float32, device=dev)
         gs = torch.zeros((2, E, 7), dtype=torch.float32, device=dev)
-    ws = _workspace(_m.lib().mslam_gn_workspace_bytes(P, E, HW), dev)
+    ws = _workspace(_m.lib().mslam_gn_workspace_bytes(P, E, HW, int(edge_count)), dev)
     L = _m.lib()
     _m.check(L.mslam_gn_begin(_m.ptr(ii), _m.ptr(jj), P, E, HW, _m.ptr(ws), ws.numel(), _m.stream_ptr()), "gn_begin")
+    rc = L.mslam_gn_compact(
+        _m.ptr(Xs), _m.ptr(Cs), _m.ptr(idx_ii2jj), _m.ptr(valid_match), _m.ptr(Q), P, HW, E, int(edge_begin),
+        int(edge_count), float(C_thresh), float(Q_thresh), _m.ptr(ws), ws.numel(), _m.stream_ptr())
+    _m.check(rc, "gn_compact")
     rc = L.mslam_gn_accumulate(
-        _KIND[kind], _m.ptr(Twc), _m.ptr(Xs), _m.ptr(Cs), _m.ptr(K), _m.ptr(idx_ii2jj), _m.ptr(valid_match),
-        _m.ptr(Q), P, HW, E, int(edge_begin), int(edge_count), float(sigma_a), float(sigma_b), float(C_thresh),
-        float(Q_thresh), int(height), int(width), int(pixel_border), float(z_eps), _m.ptr(Hs), _m.ptr(gs),
+        _KIND[kind], _m.ptr(Twc), _m.ptr(K), P, HW, E, int(edge_begin), int(edge_count), float(sigma_a),
+        float(sigma_b), int(height), int(width), int(pixel_border), float(z_eps), _m.ptr(Hs), _m.ptr(gs),
         _m.ptr(ws), ws.numel(), _m.stream_ptr(),
     )
     _m.check(rc, "gn_accumulate")

@@ -31,7 +31,8 @@ _SIGNATURES = {
     "mslam_gauss_newton_calib": [_c_vp] * 9 + [_c_int] * 6 + [_c_float] * 5 + [_c_int, _c_float, _c_vp, _c_vp, _c_size, _c_vp],
     "mslam_gauss_newton_points": [_c_vp] * 8 + [_c_int] * 3 + [_c_float] * 3 + [_c_int, _c_float, _c_vp, _c_vp, _c_size, _c_vp],
     "mslam_gn_begin": [_c_vp] * 2 + [_c_int] * 3 + [_c_vp, _c_size, _c_vp],
-    "mslam_gn_accumulate": [_c_int] + [_c_vp] * 7 + [_c_int] * 5 + [_c_float] * 4 + [_c_int] * 3 + [_c_float] + [_c_vp] * 3 + [_c_size, _c_vp],
+    "mslam_gn_compact": [_c_vp] * 5 + [_c_int] * 5 + [_c_float] * 2 + [_c_vp, _c_size, _c_vp],
+    "mslam_gn_accumulate": [_c_int] + [_c_vp] * 2 + [_c_int] * 5 + [_c_float] * 2 + [_c_int] * 3 + [_c_float] + [_c_vp] * 3 + [_c_size, _c_vp],
     "mslam_gn_solve_retract": [_c_vp] * 2 + [_c_int] * 3 + [_c_vp, _c_vp, _c_float, _c_vp, _c_size, _c_vp],
     "mslam_gn_status": [_c_vp] + [_c_int] * 3 + [_c_vp, _c_size, _c_vp],
     "mslam_sim3_act": [_c_vp] * 3 + [_c_int, ctypes.c_longlong, _c_int, _c_vp],
@@ -90,7 +91,7 @@ def lib() -> ctypes.CDLL:
             fn.restype = ctypes.c_int
         handle.mslam_last_error.argtypes = []
         handle.mslam_last_error.restype = ctypes.c_char_p
-        handle.mslam_gn_workspace_bytes.argtypes = [_c_int] * 3
+        handle.mslam_gn_workspace_bytes.argtypes = [_c_int] * 4
         handle.mslam_gn_workspace_bytes.restype = ctypes.c_size_t
         handle.mslam_mast3r_workspace_bytes.argtypes = [_c_vp, _c_int, _c_int, _c_int]
         handle.mslam_mast3r_workspace_bytes.restype = ctypes.c_size_t

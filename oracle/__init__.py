@@ -168,6 +168,13 @@ def sim3_retr(xi, T):
     return out
 
 
+def sim3_retr_rows(dx, Twc, num_fix=1):
+    """pose_retr_kernel (gn_kernels.cu:415-453): rows >= num_fix of Twc retracted by dx (P-num_fix,7)."""
+    out = np.array(Twc, np.float32, copy=True)
+    out[num_fix:] = sim3_retr(dx, out[num_fix:])
+    return out
+
+
 def sim3_rel(Ti, Tj):
     Ti = _c(Ti, np.float32).reshape(-1, 8); Tj = _c(Tj, np.float32).reshape(-1, 8)
     out = np.zeros_like(Ti)
