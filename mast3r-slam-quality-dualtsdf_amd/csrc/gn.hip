@@ -167,9 +167,14 @@ __global__ __launch_bounds__(256) void gn_compact_kernel(
 // ---------------------------------------------------------------------------------------------
 // streaming accumulation
 // ---------------------------------------------------------------------------------------------
+// v_rcp_f32 / v_rsq_f32 (1 ulp) instead of the correctly rounded division / square root the translation
+// unit is otherwise built with: the blocks are compared at rel-L2 1e-5, and an IEEE division costs ten
+// instructions in a loop whose arithmetic is as long as its memory time.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 __device__ __forceinline__ float huber_w(float r) {
-  const float a = fabsf(r);
-  return a < 1.345f ? 1.0f : 1.345f / a;
+  return fminf(1.0f, 1.345f * fast_rcp(fabsf(r)));  // == (a < 1.345 ? 1 : 1.345 / a), branch-free
 }
 
 // acc[0..27] += w * x x^T (lower triangle, row-major n>=m), acc[28..34] += w*err*x.
@@ -215,11 +220,11 @@ __device__ __forceinline__ void gn_point(float (&acc)[kAcc], const EdgeConst& c,
   const float p2 = fmaf(c.r20, xj0, fmaf(c.r21, xj1, fmaf(c.r22, xj2, c.t2)));
   if constexpr (KIND == 0) {
     const float n2i = fmaf(xi2, xi2, fmaf(xi1, xi1, xi0 * xi0));
-    const float n1i = sqrtf(n2i);
-    const float n1i_inv = 1.0f / n1i;
+    const float n1i_inv = fast_rsq(n2i);
+    const float n1i = n2i * n1i_inv;
     const float n2j = fmaf(p2, p2, fmaf(p1, p1, p0 * p0));
-    const float n1j = sqrtf(n2j);
-    const float n1j_inv = 1.0f / n1j;
+    const float n1j_inv = fast_rsq(n2j);
+    const float n1j = n2j * n1j_inv;
     const float rj0 = p0 * n1j_inv, rj1 = p1 * n1j_inv, rj2 = p2 * n1j_inv;
     const float e0 = rj0 - xi0 * n1i_inv, e1 = rj1 - xi1 * n1i_inv, e2 = rj2 - xi2 * n1i_inv;
     const float e3 = n1j - n1i;
@@ -228,7 +233,7 @@ __device__ __forceinline__ void gn_point(float (&acc)[kAcc], const EdgeConst& c,
     const float wr = swr * swr, wd = swd * swd;
     const float w0 = huber_w(swr * e0) * wr, w1 = huber_w(swr * e1) * wr, w2 = huber_w(swr * e2) * wr;
     const float w3 = huber_w(swd * e3) * wd;
-    const float n3 = n1j_inv / n2j;
+    const float n3 = n1j_inv * n1j_inv * n1j_inv;
     const float dxx = n1j_inv - p0 * p0 * n3, dyy = n1j_inv - p1 * p1 * n3, dzz = n1j_inv - p2 * p2 * n3;
     const float dxy = -p0 * p1 * n3, dxz = -p0 * p2 * n3, dyz = -p1 * p2 * n3;
     {
@@ -251,7 +256,7 @@ __device__ __forceinline__ void gn_point(float (&acc)[kAcc], const EdgeConst& c,
     const float Pfx = P.K[0], Pfy = P.K[4], Pcx = P.K[2], Pcy = P.K[5];
     const int u_t = ind % P.width, v_t = ind / P.width;
     const bool valid_z = (p2 > P.z_eps) && (xi2 > P.z_eps);
-    const float zinv = valid_z ? 1.0f / p2 : 0.0f;
+    const float zinv = valid_z ? fast_rcp(p2) : 0.0f;
     const float zj_log = valid_z ? logf(p2) : 0.0f;
     const float zi_log = valid_z ? logf(xi2) : 0.0f;
     const float xz = p0 * zinv, yz = p1 * zinv;
@@ -316,8 +321,10 @@ __global__ __launch_bounds__(256) void gn_accum_kernel(const GnState* __restrict
 #pragma unroll
   for (int l = 0; l < kAcc; l++) acc[l] = 0.0f;
 
-  // four consecutive points per lane and round: one 16-B load per plane
-  for (int k = (int)threadIdx.x * 4; k < n; k += 1024) {
+  // four consecutive points per lane and round: one 16-B load per plane, no per-point predicate in the
+  // main loop (a predicate makes the compiler sink the loads into four branches and split them)
+  const int n4 = n & ~3;
+  for (int k = (int)threadIdx.x * 4; k < n4; k += 1024) {
     float f[kPlanes][4];
 #pragma unroll
     for (int p = 0; p < kPlanes; p++) {
@@ -329,11 +336,16 @@ __global__ __launch_bounds__(256) void gn_accum_kernel(const GnState* __restrict
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (k + j < n)
-        gn_point<KIND>(acc, c, P, f[0][j], f[1][j], f[2][j], f[3][j], f[4][j], f[5][j], f[6][j],
-                       KIND == 1 ? __float_as_int(f[7][j]) : 0);
-    }
+    for (int j = 0; j < 4; j++)
+      gn_point<KIND>(acc, c, P, f[0][j], f[1][j], f[2][j], f[3][j], f[4][j], f[5][j], f[6][j],
+                     KIND == 1 ? __float_as_int(f[7][j]) : 0);
+  }
+  if ((int)threadIdx.x < n - n4) {  // the <= 3 points behind the last full group
+    const int k = n4 + (int)threadIdx.x;
+    const float* q = slot + k;
+    gn_point<KIND>(acc, c, P, q[0], q[(size_t)chunk_len], q[2 * (size_t)chunk_len], q[3 * (size_t)chunk_len],
+                   q[4 * (size_t)chunk_len], q[5 * (size_t)chunk_len], q[6 * (size_t)chunk_len],
+                   KIND == 1 ? __float_as_int(q[7 * (size_t)chunk_len]) : 0);
   }
 
   // wave64 shuffle reduction, then one LDS pass over the 4 waves
@@ -502,12 +514,15 @@ __global__ __launch_bounds__(64) void gn_assemble_kernel(const GnState* __restri
 // ---------------------------------------------------------------------------------------------
 // chol_step<NB>(j0): panel j0 (columns j0..j0+NB, rows below its diagonal block) is final.  Every 64x64
 // tile of the lower triangle of the trailing matrix (rows j1..np INCLUDING the rhs row np, columns
-// j1..np-1, j1 = j0 + NB) gets the rank-NB update A -= L_i L_j^T on the f64 matrix cores.  The tiles of
-// the first tile column additionally finish the NEXT panel (columns j1..j1+NB): each of them computes
-// the updated diagonal block D = A11 - Lp Lp^T itself (same code in every workgroup: identical bits),
-// factors it in LDS and solves its own rows X L11^T = A21'.  Nobody writes A11 in this launch (the other
+// j1..np-1, j1 = j0 + NB) gets the rank-NB update A -= L_i L_j^T on the f64 matrix cores (the tile is
+// loaded straight into the accumulators, the A operand is negated).  The tiles of the first tile
+// column additionally finish the NEXT panel (columns j1..j1+NB): each of them computes the updated
+// diagonal block D = A11 - Lp Lp^T itself (same code in every workgroup: identical bits), factors it
+// in LDS and solves its own rows X L11^T = A21'.  Nobody writes A11 in this launch (the other
 // workgroups read it): the factor of the diagonal block goes to the side array Ldiag[panel].
 // j0 = -NB is the prologue: no update, only the first panel is finished.
+// Every global load of a workgroup is issued in ONE phase at its start (the launch is latency-bound:
+// 28 dependent launches per factorisation at 125 keyframes).
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 template <int NB>
@@ -524,59 +539,72 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
   if (r0 > np || c0 >= np) return;
   const bool has_update = j0 >= 0;
   extern __shared__ double sh[];
-  double* Li = sh;                        // [64][LS]
-  double* Lj = sh + kTile * LS;           // [64][LS]
+  double* Li = sh;                        // [64][LS] rows r0.. of panel j0
+  double* Lj = sh + kTile * LS;           // [64][LS] rows c0.. of panel j0 (first tile column: rows j1.. = Lp)
   double* T = sh;                         // [64][TS] aliases Li/Lj after the MFMA loop (first tile column)
   double* D = sh + 2 * kTile * LS;        // [NB][DS]
+  double* dsave = D + NB * DS;            // [NB] sqrt of the pivots
+  double* rdiag = dsave + NB;             // [NB] their reciprocals
   __shared__ int fail;
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const int fcol = lane & 15, frow = lane >> 4;
 
-  // ---- first tile column: D = A11 - Lp Lp^T (before the panel rows overwrite the scratch) ----
+  // ---- one load phase: the tile into the accumulators, panel rows (and A11) into LDS ----
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int r = r0 + 32 * wr + 16 * m + frow + 4 * g;
+        const int c = c0 + 32 * wc + 16 * n + fcol;
+        const bool in = r <= np && c < np && c <= r;
+        const double v = A[in ? (size_t)r * ld + c : (size_t)0];  // always-valid address + select: no branch
+        acc[m][n][g] = in ? v : 0.0;
+      }
+  if (has_update) {
+    for (int k = t; k < kTile * NB; k += 256) {
+      const int r = k / NB, q = k % NB;
+      const double vi = A[(size_t)min(r0 + r, np) * ld + j0 + q];
+      const double vj = A[(size_t)min(c0 + r, np) * ld + j0 + q];
+      Li[r * LS + q] = (r0 + r <= np) ? vi : 0.0;
+      Lj[r * LS + q] = (c0 + r < np) ? vj : 0.0;
+    }
+  }
   if (tj == 0) {
-    double* Lp = sh;  // [NB][LS]
     for (int k = t; k < NB * NB; k += 256) {
       const int a = k / NB, b = k % NB;
       D[a * DS + b] = A[(size_t)(j1 + a) * ld + j1 + b];
-      Lp[a * LS + b] = has_update ? A[(size_t)(j1 + a) * ld + j0 + b] : 0.0;
     }
     if (t == 0) fail = 0;
-    __syncthreads();
-    if (has_update) {
+  }
+  __syncthreads();
+
+  if (has_update) {
+    // first tile column: D = A11 - Lp Lp^T with Lp = rows j1..j1+NB of the panel = the first NB rows of Lj
+    if (tj == 0) {
       for (int k = t; k < NB * NB; k += 256) {
         const int a = k / NB, b = k % NB;
         if (b <= a) {
           double s = 0.0;
 #pragma unroll 8
-          for (int q = 0; q < NB; q++) s = fma(Lp[a * LS + q], Lp[b * LS + q], s);
+          for (int q = 0; q < NB; q++) s = fma(Lj[a * LS + q], Lj[b * LS + q], s);
           D[a * DS + b] -= s;
         }
       }
     }
-    __syncthreads();
-  }
-
-  // ---- rank-NB update of this tile on the matrix cores ----
-  f64x4 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-  const int wr = wid >> 1, wc = wid & 1;
-  if (has_update) {
-    for (int k = t; k < kTile * NB; k += 256) {
-      const int r = k / NB, q = k % NB;
-      Li[r * LS + q] = (r0 + r <= np) ? A[(size_t)(r0 + r) * ld + j0 + q] : 0.0;
-      Lj[r * LS + q] = (c0 + r < np) ? A[(size_t)(c0 + r) * ld + j0 + q] : 0.0;
-    }
-    __syncthreads();
+    // rank-NB update of the tile on the matrix cores: acc += (-Li) Lj^T
     const int fi = lane & 15, fk = lane >> 4;
 #pragma unroll 4
     for (int k4 = 0; k4 < NB; k4 += 4) {
       double a[2], b[2];
 #pragma unroll
       for (int m = 0; m < 2; m++) {
-        a[m] = Li[(32 * wr + 16 * m + fi) * LS + k4 + fk];
+        a[m] = -Li[(32 * wr + 16 * m + fi) * LS + k4 + fk];
         b[m] = Lj[(32 * wc + 16 * m + fi) * LS + k4 + fk];
       }
 #pragma unroll
@@ -585,26 +613,26 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
         for (int n = 0; n < 2; n++)
           acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
     }
-    __syncthreads();  // all fragment reads done: T may alias Li/Lj
   }
 
-  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-  const int fcol = lane & 15, frow = lane >> 4;
   if (tj != 0) {
+    if (has_update) {
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+      for (int m = 0; m < 2; m++)
 #pragma unroll
-      for (int n = 0; n < 2; n++)
+        for (int n = 0; n < 2; n++)
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int r = r0 + 32 * wr + 16 * m + frow + 4 * g;
-          const int c = c0 + 32 * wc + 16 * n + fcol;
-          if (r <= np && c < np && c <= r) A[(size_t)r * ld + c] -= acc[m][n][g];
-        }
+          for (int g = 0; g < 4; g++) {
+            const int r = r0 + 32 * wr + 16 * m + frow + 4 * g;
+            const int c = c0 + 32 * wc + 16 * n + fcol;
+            if (r <= np && c < np && c <= r) A[(size_t)r * ld + c] = acc[m][n][g];
+          }
+    }
     return;
   }
 
-  // ---- first tile column: updated values into T; columns beyond the panel go straight back ----
+  // ---- first tile column: panel columns into T, columns beyond the panel straight back ----
+  __syncthreads();  // all fragment reads of Li / Lj and the D update are done: T may alias them
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -614,41 +642,57 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
         const int rr = 32 * wr + 16 * m + frow + 4 * g;
         const int cc = 32 * wc + 16 * n + fcol;
         const int r = r0 + rr, c = c0 + cc;
-        double v = 0.0;
-        if (r <= np && c < np && c <= r) v = A[(size_t)r * ld + c] - acc[m][n][g];
-        if (cc < NB) T[rr * TS + cc] = v;
-        else if (r <= np && c < np && c <= r) A[(size_t)r * ld + c] = v;
+        if (cc < NB) T[rr * TS + cc] = acc[m][n][g];
+        else if (has_update && r <= np && c < np && c <= r) A[(size_t)r * ld + c] = acc[m][n][g];
       }
 
-  // ---- factor D in LDS (every workgroup of the column: same bits) ----
-  for (int j = 0; j < NB; j++) {
-    __syncthreads();
-    if (t == 0) {
-      const double d = D[j * DS + j];
-      if (!(d > 0.0)) { fail = 1; D[j * DS + j] = 1.0; }
-      else D[j * DS + j] = sqrt(d);
-    }
-    __syncthreads();
-    const double dj = D[j * DS + j];
-    if (t > j && t < NB) D[t * DS + j] /= dj;
-    __syncthreads();
-    const int rem = NB - j - 1;
-    for (int k = t; k < rem * rem; k += 256) {
-      const int r = j + 1 + k / rem, c = j + 1 + k % rem;
-      if (c <= r) D[r * DS + c] -= D[r * DS + j] * D[c * DS + j];
-    }
-  }
+  // ---- factor D in LDS (every workgroup of the column: same bits), two barriers per pivot ----
   __syncthreads();
+  for (int j = 0; j < NB; j++) {
+    const double djj = D[j * DS + j];
+    const bool ok = djj > 0.0;
+    double d, rinv;
+    if (djj > 1e-30 && djj < 1e30) {
+      // 1/sqrt by Newton from the f32 seed (three steps: 24 -> 48 -> 53+ bits); the library sqrt + division
+      // are ~400 cycles of dependent latency per pivot on the critical path of every launch
+      double r = (double)__builtin_amdgcn_rsqf((float)djj);
+      const double h = 0.5 * djj;
+      r = r * (1.5 - h * r * r);
+      r = r * (1.5 - h * r * r);
+      r = r * (1.5 - h * r * r);
+      rinv = r;
+      d = djj * r;
+    } else {
+      d = ok ? sqrt(djj) : 1.0;
+      rinv = 1.0 / d;
+    }
+    if (t > j && t < NB) D[t * DS + j] *= rinv;
+    if (t == j) {
+      dsave[j] = d;
+      rdiag[j] = rinv;
+      if (!ok) fail = 1;
+    }
+    __syncthreads();
+    // rank-1 update of the trailing lower triangle; (row, column) from the element index by shifts
+#pragma unroll
+    for (int i = 0; i < NB * NB / 256; i++) {
+      const int k = t + 256 * i;
+      const int r = k / NB, c = k % NB;
+      if (c > j && c <= r) D[r * DS + c] -= D[r * DS + j] * D[c * DS + j];
+    }
+    __syncthreads();
+  }
   if (ti == 0) {
     if (fail && t == 0) st->chol_fail = 1;
     double* Ld = Ldiag + (size_t)(j1 / NB) * NB * NB;
     for (int k = t; k < NB * NB; k += 256) {
       const int a = k / NB, b = k % NB;
-      Ld[k] = (b <= a) ? D[a * DS + b] : 0.0;
+      Ld[k] = (b < a) ? D[a * DS + b] : (b == a ? dsave[a] : 0.0);
     }
   }
 
-  // ---- rows of the panel below its diagonal block: x L11^T = t, one row per lane of wave 0 ----
+  // ---- rows of the panel below its diagonal block: x L11^T = t, one row per lane of wave 0; the result
+  // goes back through T so that the global stores are whole 256-B row segments ----
   if (t < kTile) {
     const int r = r0 + t;
     const bool in_diag = (ti == 0) && (t < NB);
@@ -661,18 +705,24 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
         double s = x[c];
 #pragma unroll
         for (int k = 0; k < c; k++) s -= x[k] * D[c * DS + k];
-        x[c] = s / D[c * DS + c];
+        x[c] = s * rdiag[c];
       }
-      double* row = A + (size_t)r * ld + j1;
 #pragma unroll
-      for (int c = 0; c < NB; c++) row[c] = x[c];
+      for (int c = 0; c < NB; c++) T[t * TS + c] = x[c];
     }
+  }
+  __syncthreads();
+  for (int k = t; k < kTile * NB; k += 256) {
+    const int rr = k / NB, c = k % NB;
+    const int r = r0 + rr;
+    const bool in_diag = (ti == 0) && (rr < NB);
+    if (r <= np && !in_diag) A[(size_t)r * ld + j1 + c] = T[rr * TS + c];
   }
 }
 
 // back substitution L^T x = y (y = row np), one launch per panel from the last to the first: every
 // workgroup solves the panel's NB unknowns itself (column-oriented, one wave) and then removes them
-// from its 256 entries of y above the panel.  x goes to xs (np doubles).
+// from its 256 entries of y above the panel.  x goes to xs (np doubles).  Used above kBackSmall unknowns.
 template <int NB>
 __global__ __launch_bounds__(256) void chol_back_kernel(const GnState* __restrict__ st,
                                                         double* __restrict__ A,
@@ -688,10 +738,9 @@ __global__ __launch_bounds__(256) void chol_back_kernel(const GnState* __restric
   __syncthreads();
   if (t < 64) {
     double s = t < NB ? y[jb + t] : 0.0;
+    const double rd = t < NB ? 1.0 / Lb[t][t] : 0.0;
     for (int c = NB - 1; c >= 0; c--) {
-      double xc = 0.0;
-      if (t == c) xc = s / Lb[c][c];
-      xc = __shfl(xc, c, 64);
+      const double xc = __shfl(s * rd, c, 64);
       if (t == c) xb[c] = xc;
       if (t < c) s -= Lb[c][t] * xc;
     }
@@ -704,6 +753,47 @@ __global__ __launch_bounds__(256) void chol_back_kernel(const GnState* __restric
 #pragma unroll 8
     for (int k = 0; k < NB; k++) s -= A[(size_t)(jb + k) * ld + i] * xb[k];  // rows of L: contiguous in i
     y[i] = s;
+  }
+}
+
+// the same back substitution as ONE workgroup and ONE launch while y fits in LDS (np <= kBackSmall):
+// panel after panel, y never leaves LDS.
+constexpr int kBackSmall = 2048;
+
+template <int NB>
+__global__ __launch_bounds__(256) void chol_back_small_kernel(const GnState* __restrict__ st,
+                                                              const double* __restrict__ A,
+                                                              const double* __restrict__ Ldiag,
+                                                              double* __restrict__ xs, int np, int ld) {
+  if (st->done) return;
+  __shared__ double ys[kBackSmall];
+  __shared__ double Lb[NB][NB + 1];
+  __shared__ double xb[NB];
+  const int t = threadIdx.x;
+  for (int i = t; i < np; i += 256) ys[i] = A[(size_t)np * ld + i];
+  for (int jb = np - NB; jb >= 0; jb -= NB) {
+    const double* Ld = Ldiag + (size_t)(jb / NB) * NB * NB;
+    for (int k = t; k < NB * NB; k += 256) Lb[k / NB][k % NB] = Ld[k];
+    __syncthreads();  // Lb loaded; ys of this panel final
+    if (t < 64) {
+      double s = t < NB ? ys[jb + t] : 0.0;
+      const double rd = t < NB ? 1.0 / Lb[t][t] : 0.0;
+      for (int c = NB - 1; c >= 0; c--) {
+        const double xc = __shfl(s * rd, c, 64);
+        if (t == c) xb[c] = xc;
+        if (t < c) s -= Lb[c][t] * xc;
+      }
+    }
+    __syncthreads();
+    if (t < NB) xs[jb + t] = xb[t];
+    for (int i = t; i < jb; i += 256) {
+      double s = ys[i];
+#pragma unroll 8
+      for (int k = 0; k < NB; k++) s -= A[(size_t)(jb + k) * ld + i] * xb[k];
+      ys[i] = s;
+    }
+    // the next round's first barrier orders these writes (and the reads of Lb / xb) before their reuse
+    __syncthreads();
   }
 }
 
@@ -848,7 +938,7 @@ static int launch_accumulate(int kind, const GnWorkspace& w, const float* Twc, i
 
 template <int NB>
 static int launch_cholesky(const GnWorkspace& w, hipStream_t s) {
-  constexpr size_t shmem = sizeof(double) * (2 * kTile * (NB + 2) + NB * (NB + 1));
+  constexpr size_t shmem = sizeof(double) * (2 * kTile * (NB + 2) + NB * (NB + 1) + 2 * NB);
   static bool attr_set = false;
   if (shmem > 48 * 1024 && !attr_set) {
     int rc = check_hip(hipFuncSetAttribute((const void*)chol_step_kernel<NB>,
@@ -864,10 +954,14 @@ static int launch_cholesky(const GnWorkspace& w, hipStream_t s) {
     hipLaunchKernelGGL(chol_step_kernel<NB>, dim3(tiles_c, tiles_r), dim3(256), shmem, s, w.st, w.Haug, w.Ldiag,
                        w.np, w.ld, j0);
   }
-  for (int jb = w.np - NB; jb >= 0; jb -= NB) {
-    const int blocks = jb > 0 ? (jb + 255) / 256 : 1;
-    hipLaunchKernelGGL(chol_back_kernel<NB>, dim3(blocks), dim3(256), 0, s, w.st, w.Haug, w.Ldiag, w.xs, w.np,
-                       w.ld, jb);
+  if (w.np <= kBackSmall) {
+    hipLaunchKernelGGL(chol_back_small_kernel<NB>, dim3(1), dim3(256), 0, s, w.st, w.Haug, w.Ldiag, w.xs, w.np, w.ld);
+  } else {
+    for (int jb = w.np - NB; jb >= 0; jb -= NB) {
+      const int blocks = jb > 0 ? (jb + 255) / 256 : 1;
+      hipLaunchKernelGGL(chol_back_kernel<NB>, dim3(blocks), dim3(256), 0, s, w.st, w.Haug, w.Ldiag, w.xs, w.np,
+                         w.ld, jb);
+    }
   }
   return MSLAM_OK;
 }
