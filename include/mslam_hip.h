@@ -178,6 +178,10 @@ int mslam_tsdf_integrate(void* table, uint64_t capacity, const float* points_wor
 
 /* out8_host <- {voxels, overflow flag, records of last integrate, voxels touched, points fused
  * (integrate's return value), dump cursor, capacity lo, capacity hi}.  SYNCHRONISES the stream. */
+/* Growth of the voxel hash (the reference's dict is unbounded, global_volume.py:27): moves every voxel of `old_table`
+ * into `new_table` (initialised by mslam_tsdf_table_init, capacity >= the old one) with value, weight and first-touch
+ * state.  Call between integrate calls; the host side (TSDFVolume.maintain) does so when the load exceeds 1/2. */
+int mslam_tsdf_rehash(void* old_table, uint64_t old_capacity, void* new_table, uint64_t new_capacity, void* stream);
 int mslam_tsdf_header(void* table, uint64_t capacity, uint32_t* out8_host, void* stream);
 
 /* Dict contents (TSDFVolume._voxels): keys i64[max_out,3], tsdf f64, weight f64, unordered. */
@@ -262,6 +266,12 @@ int mslam_gemm_bf16(const void* A, const void* W, const float* bias, const void*
  * for every plain GEMM of exactly this shape (M < 0: the implicit-conv GEMM of shape |M| x N x K), process-wide.  tools/insitu_tune.py uses it to time whole network
  * stages under alternative tilings; results do not depend on the tiling (same K order per output element). */
 int mslam_gemm_tile_override(int M, int N, int K, int cfg);
+/* Measurement hook (bench.py `roofline`): between begin and end every launch of the plain GEMM of exactly this
+ * shape - from any entry point, on any stream - is bracketed by two HIP events recorded on the stream it is
+ * launched on (at most max_samples launches).  end() waits for the recorded events and returns the average and
+ * minimum launch duration in microseconds (host doubles / int). */
+int mslam_gemm_profile_begin(int M, int N, int K, int max_samples);
+int mslam_gemm_profile_end(double* avg_us, double* min_us, int* samples);
 /* NHWC bf16 conv (ks 1|3, stride 1|2, pad ks/2), W bf16 [Cout, ks*ks*Cin] tap-major; optional ReLU on
  * the input, act on the output, bf16 residual added after act. */
 int mslam_conv2d_nhwc_bf16(const void* in, const void* W, const float* bias, const void* residual_bf16,

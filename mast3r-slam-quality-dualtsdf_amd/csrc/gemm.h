@@ -63,6 +63,8 @@ struct GemmArgs {
 constexpr int kGemmPrefetchBlocks = 64;   // x 256+ lanes x 16 loads x 16 B = 4 MiB in flight
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+int gemm_profile_begin(int M, int N, int K, int max_samples);   // see gemm.hip
+int gemm_profile_end(double* avg_us, double* min_us, int* samples);
 int gemm_tile_override(int M, int N, int K, int cfg, bool conv);   // cfg codes of gemm.hip; 0 removes the entry
 
 }  // namespace mslam

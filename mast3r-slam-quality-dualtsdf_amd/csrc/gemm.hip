@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 #include "common.h"
 #include "gemm.h"
 
@@ -11,6 +12,7 @@ int launch_gemm_t64(const GemmArgs& a, int stages, hipStream_t s);
 int launch_gemm_t128(const GemmArgs& a, int waves, int stages, hipStream_t s);
 int launch_gemm_t128x64(const GemmArgs& a, int stages, hipStream_t s);
 int launch_gemm_t256(const GemmArgs& a, int bn, hipStream_t s);
+int launch_gemm_t192(const GemmArgs& a, hipStream_t s);
 
 // Per-shape tile choices for plain (non-conv, ungrouped) problems: the measured table below, editable at run time
 // through mslam_gemm_tile_override (tools/insitu_tune.py finds the entries by timing whole network stages).
@@ -23,6 +25,9 @@ static std::unordered_map<uint64_t, int> g_tile_override = {
     {tile_key(3072, 3072, 1024), 1262},   // encoder qkv at a frame group of 4: 128x64 tiles instead of 144 tiles of 256x256
     {tile_key(3072, 768, 3072), 643},     // decoder fc2 at a frame group of 4: ring of 3
     {tile_key(6144, 3072, 768), 1282},    // decoder fc1 of the batch-8 backend call: 288 tiles of 256x256 leave a half-empty round
+    // round 2 (tools/gemm_cfg_ab.py, interleaved A/B in one process, profiles/r02_gemm_cfg_ab.log)
+    {tile_key(3072, 4096, 1024), 2192},   // encoder fc1 at a frame group of 4: 16 x 16 tiles of 192x256 = one per CU (256x256: 192 tiles)
+    {tile_key(6144, 4096, 1024), 1282},   // the same at a group of 8: 384 tiles of 256x256 are one and a half rounds
 };
 
 int gemm_tile_override(int M, int N, int K, int cfg, bool conv) {
@@ -32,7 +37,68 @@ int gemm_tile_override(int M, int N, int K, int cfg, bool conv) {
   return 0;
 }
 
+// Live per-launch timing of ONE shape (bench.py's `roofline` object): while enabled, every launch of the chosen plain
+// (M, N, K) problem is bracketed by two HIP events on the stream it is launched on; read back after the timed region.
+static std::mutex g_prof_mu;
+static struct {
+  bool on = false;
+  int M = 0, N = 0, K = 0, cap = 0, n = 0;
+  std::vector<hipEvent_t> ev;   // 2 * cap
+} g_prof;
+
+int gemm_profile_begin(int M, int N, int K, int max_samples) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  MSLAM_REQUIRE(!g_prof.on, "gemm_profile_begin: already profiling");
+  MSLAM_REQUIRE(max_samples > 0 && max_samples <= 65536, "gemm_profile_begin: max_samples out of range");
+  g_prof.ev.resize(2 * (size_t)max_samples);
+  for (auto& e : g_prof.ev) {
+    int rc = check_hip(hipEventCreate(&e), "hipEventCreate");
+    if (rc) return rc;
+  }
+  g_prof.M = M; g_prof.N = N; g_prof.K = K; g_prof.cap = max_samples; g_prof.n = 0;
+  g_prof.on = true;
+  return MSLAM_OK;
+}
+
+int gemm_profile_end(double* avg_us, double* min_us, int* samples) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  MSLAM_REQUIRE(g_prof.on, "gemm_profile_end: not profiling");
+  g_prof.on = false;
+  double sum = 0.0, mn = 1e30;
+  int rc = MSLAM_OK;
+  for (int i = 0; i < g_prof.n && !rc; i++) {
+    float ms = 0.0f;
+    rc = check_hip(hipEventSynchronize(g_prof.ev[2 * i + 1]), "hipEventSynchronize");
+    if (!rc) rc = check_hip(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]), "hipEventElapsedTime");
+    sum += 1e3 * ms;
+    if (1e3 * ms < mn) mn = 1e3 * ms;
+  }
+  if (samples) *samples = g_prof.n;
+  if (avg_us) *avg_us = g_prof.n ? sum / g_prof.n : 0.0;
+  if (min_us) *min_us = g_prof.n ? mn : 0.0;
+  for (auto& e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  return rc;
+}
+
+static int launch_gemm_impl(const GemmArgs& a, hipStream_t stream);
+
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+  int slot = -1;
+  if (g_prof.on) {   // racy read is fine: begin/end are called with the GPU idle
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.on && !a.a_conv && a.groups <= 1 && a.M == g_prof.M && a.N == g_prof.N && a.K == g_prof.K &&
+        g_prof.n < g_prof.cap) {
+      slot = g_prof.n++;
+      (void)hipEventRecord(g_prof.ev[2 * slot], stream);
+    }
+  }
+  const int rc = launch_gemm_impl(a, stream);
+  if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], stream);
+  return rc;
+}
+
+static int launch_gemm_impl(const GemmArgs& a, hipStream_t stream) {
   MSLAM_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %dx%dx%d", a.M, a.N, a.K);
   MSLAM_REQUIRE(a.K % 8 == 0, "gemm: K=%d must be a multiple of 8", a.K);
   MSLAM_REQUIRE(!a.a_conv || a.cC % 8 == 0, "gemm: conv channels %d must be a multiple of 8", a.cC);
@@ -49,7 +115,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   // traffic and win as soon as they still cover the chip.
   // MSLAM_GEMM="<cfg>" forces one configuration for experiments:
   //   642/643/644: 64x64 ring 2/3/4; 1262/1263: 128x64 ring 2/3; 1242: 128x128 4 waves; 1282/1283: 128x128 8 waves ring 2/3;
-  //   2128: 256x128 8 waves; 2256: 256x256 16 waves
+  //   2128: 256x128 8 waves; 2256: 256x256 16 waves; 2192: 192x256 8 waves
   static int forced = -2;
   if (forced == -2) {
     const char* e = getenv("MSLAM_GEMM");
@@ -88,6 +154,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     case 1283: return launch_gemm_t128(a, 8, 3, stream);
     case 2128: return launch_gemm_t256(a, 128, stream);
     case 2256: return launch_gemm_t256(a, 256, stream);
+    case 2192: return launch_gemm_t192(a, stream);
     default: MSLAM_REQUIRE(false, "gemm: unknown configuration %d", cfg);
   }
 }

@@ -1164,7 +1164,7 @@ __global__ void sim3_unary_kernel(int op, const float* __restrict__ A, const flo
   } else {  // retr: exp(A=xi) * B
     R = sim3_retr(A + 7 * (bcast_a ? 0 : i), sim3_load(B + 8 * (bcast_b ? 0 : i)));
   }
-  sim3_store(O + 8 * i, R);
+  sim3_store(O + 8 * i, sim3_unit(R));   // lietorch normalises the quaternion of every group element it constructs
 }
 }  // namespace mslam
 

@@ -1167,6 +1167,14 @@ extern "C" int mslam_gemm_tile_override(int M, int N, int K, int cfg) {
   return gemm_tile_override(M < 0 ? -M : M, N, K, cfg, M < 0);
 }
 
+extern "C" int mslam_gemm_profile_begin(int M, int N, int K, int max_samples) {
+  return gemm_profile_begin(M, N, K, max_samples);
+}
+
+extern "C" int mslam_gemm_profile_end(double* avg_us, double* min_us, int* samples) {
+  return gemm_profile_end(avg_us, min_us, samples);
+}
+
 extern "C" int mslam_gemm_bf16(const void* A, const void* Wt, const float* bias, const void* residual_f32, void* out,
                                int M, int N, int K, int act, int out_is_bf16, void* stream) {
   MSLAM_REQUIRE(A && Wt && out, "gemm_bf16: null pointer");

@@ -58,6 +58,19 @@ MSLAM_HD void sim3_act(const Sim3f& T, const float* X, float* Y) {
   Y[2] = Y[2] * T.s + T.t[2];
 }
 
+// lietorch keeps the rotation a UNIT quaternion: every SO3 / RxSO3 object it constructs - the result of inv, *, exp,
+// retr - normalises its quaternion (lietorch/include/so3.h, rxso3.h constructors).  Without it the frontend's cycle
+// T_CkCf = T_WCk^-1 * T_WCf ; T_WCf = T_WCk * T_CkCf squares the keyframe's norm error into every frame and the poses
+// stop being similarities after a few keyframe generations.  The reference's in-kernel restatement
+// (gn_kernels.cu:177-413, used by its GN kernels and here by theirs) does NOT normalise; the lietorch-surface ops
+// (mslam_sim3_op) and the loops that stand for Python-level lietorch calls (tracking retraction, TSDF pose update) do.
+MSLAM_HD Sim3f sim3_unit(Sim3f T) {
+  const float n2 = T.q[0] * T.q[0] + T.q[1] * T.q[1] + T.q[2] * T.q[2] + T.q[3] * T.q[3];
+  const float inv = 1.0f / sqrtf(n2);
+  T.q[0] *= inv; T.q[1] *= inv; T.q[2] *= inv; T.q[3] *= inv;
+  return T;
+}
+
 MSLAM_HD Sim3f sim3_inv(const Sim3f& T) {
   Sim3f I;
   I.q[0] = -T.q[0]; I.q[1] = -T.q[1]; I.q[2] = -T.q[2]; I.q[3] = T.q[3];

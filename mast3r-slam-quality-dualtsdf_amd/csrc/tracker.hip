@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void track_solve_kernel(TrackState* __restrict_
   float tau[7];
   double nn = 0.0;
   for (int i = 0; i < 7; i++) { tau[i] = (float)x[i]; nn += (double)tau[i] * tau[i]; }
-  sim3_store(T, sim3_retr(tau, sim3_load(T)));
+  sim3_store(T, sim3_unit(sim3_retr(tau, sim3_load(T))));   // T_CkCf.retr(tau) is a lietorch call (tracker.py:255)
   const float delta_norm = (float)sqrt(nn);
   st->last_delta_norm = delta_norm;
   // check_convergence (nonlinear_optimizer.py:5-25): first iteration old = inf -> rel_dec = nan -> false

@@ -99,9 +99,15 @@ __device__ __forceinline__ bool world_to_key(float px, float py, float pz, float
   return pack_key((long long)floorf(px / vs), (long long)floorf(py / vs), (long long)floorf(pz / vs), key);
 }
 
+// Probe sequences are bounded: the host keeps the load factor <= 1/2 (TSDFVolume.maintain grows and rehashes), where a
+// linear-probe cluster of kMaxProbe slots does not occur; an insert that would need more reports overflow instead of
+// scanning a multi-million-slot table.
+constexpr uint64_t kMaxProbe = 1024;
+
 __device__ __forceinline__ int64_t table_find(const TsdfTable& t, uint64_t key) {
   uint64_t s = mix64(key) & (t.cap - 1);
-  for (uint64_t probe = 0; probe < t.cap; probe++) {
+  const uint64_t limit = t.cap < kMaxProbe ? t.cap : kMaxProbe;
+  for (uint64_t probe = 0; probe < limit; probe++) {
     const uint64_t k = t.keys[s];
     if (k == key) return (int64_t)s;
     if (k == kEmptyKey) return -1;
@@ -112,7 +118,8 @@ __device__ __forceinline__ int64_t table_find(const TsdfTable& t, uint64_t key) 
 
 __device__ __forceinline__ int64_t table_insert(const TsdfTable& t, uint64_t key) {
   uint64_t s = mix64(key) & (t.cap - 1);
-  for (uint64_t probe = 0; probe < t.cap; probe++) {
+  const uint64_t limit = t.cap < kMaxProbe ? t.cap : kMaxProbe;
+  for (uint64_t probe = 0; probe < limit; probe++) {
     const uint64_t prev = atomicCAS((unsigned long long*)&t.keys[s], (unsigned long long)kEmptyKey,
                                     (unsigned long long)key);
     if (prev == kEmptyKey) { atomicAdd(&t.hdr->count, 1u); return (int64_t)s; }
@@ -135,6 +142,20 @@ __global__ void tsdf_init_kernel(void* base, uint64_t cap) {
     t.keys[i] = kEmptyKey; t.tsdf[i] = 1.0; t.weight[i] = 0.0;
     t.cnt[i] = 0; t.off[i] = 0; t.fill[i] = 0; t.state[i] = 0;
   }
+}
+
+// growth: every occupied slot of the old table moves to the (initialised, larger) new one with its value, weight and
+// first-touch state; between two integrate calls the scratch columns (cnt / off / fill) are zero.
+__global__ __launch_bounds__(256) void tsdf_rehash_kernel(void* old_base, uint64_t old_cap, void* new_base,
+                                                          uint64_t new_cap) {
+  const TsdfTable a = table_carve(old_base, old_cap), b = table_carve(new_base, new_cap);
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= old_cap) return;
+  const uint64_t key = a.keys[i];
+  if (key == kEmptyKey) return;
+  const int64_t slot = table_insert(b, key);
+  if (slot < 0) { b.hdr->overflow = 1; return; }
+  b.tsdf[slot] = a.tsdf[i]; b.weight[slot] = a.weight[i]; b.state[slot] = a.state[i];
 }
 
 struct IntegrateScratch {
@@ -188,6 +209,9 @@ __global__ __launch_bounds__(256) void tsdf_emit_kernel(void* base, uint64_t cap
   if (shard_id == 0) atomicAdd(&t.hdr->fused, 1u);
   const float d0 = r0 / L, d1 = r1 / L, d2 = r2 / L;
   const float maxd = L + truncf;
+  // A ray of more than 2^20 samples (15 km at the default 1.5 cm step) only occurs when a pose has diverged; the
+  // reference would spend minutes in np.linspace there.  The point is dropped and reported (overflow code 3).
+  if (!(maxd / stepf < 1048576.0f)) { t.hdr->overflow = 3; return; }
   int num = (int)(maxd / stepf);
   if (num < 1) num = 1;
   const float lstep = num > 1 ? maxd / (float)(num - 1) : 0.0f;
@@ -438,7 +462,7 @@ __global__ void tsdf_pose_finish_kernel(const double* __restrict__ partial, int 
     xd[r] = x / A[r][r];
   }
   for (int r = 0; r < 7; r++) delta[r] = (float)xd[r];
-  sim3_store(pose, sim3_retr(delta, sim3_load(pose)));
+  sim3_store(pose, sim3_unit(sim3_retr(delta, sim3_load(pose))));   // lietorch.Sim3.exp(delta) * pose (tsdf_optimizer.py:84-86)
 }
 
 __global__ __launch_bounds__(256) void tsdf_dump_kernel(void* base, uint64_t cap, int64_t* __restrict__ keys,
@@ -482,6 +506,18 @@ extern "C" int mslam_tsdf_table_init(void* table, size_t table_bytes_, uint64_t 
   hipLaunchKernelGGL(tsdf_init_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      table, capacity);
   MSLAM_LAUNCH_CHECK("tsdf_table_init");
+  return MSLAM_OK;
+}
+
+extern "C" int mslam_tsdf_rehash(void* old_table, uint64_t old_capacity, void* new_table, uint64_t new_capacity,
+                                 void* stream) {
+  MSLAM_REQUIRE(old_table && new_table && old_table != new_table, "tsdf_rehash: bad tables");
+  MSLAM_REQUIRE(new_capacity >= old_capacity && (new_capacity & (new_capacity - 1)) == 0 &&
+                    (old_capacity & (old_capacity - 1)) == 0,
+                "tsdf_rehash: capacities must be powers of two, new >= old");
+  hipLaunchKernelGGL(tsdf_rehash_kernel, dim3((unsigned)((old_capacity + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, old_table, old_capacity, new_table, new_capacity);
+  MSLAM_LAUNCH_CHECK("tsdf_rehash");
   return MSLAM_OK;
 }
 

@@ -84,11 +84,12 @@ class _BackendThread(threading.Thread):
 
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
-                 backend="inline"):
+                 backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False):
         self.model, self.device, self.K = model, torch.device(device), K
         self.keyframes = KeyframeStore() if keyframes is None else keyframes
         self.tracker = FrameTracker(model, self.keyframes, device)
-        self.factor_graph = FactorGraph(model, self.keyframes, K, device)
+        self.tracker.quality_service = quality_service          # main.py:246
+        self.factor_graph = FactorGraph(model, self.keyframes, K, device, shard_edges=shard_edges)
         self.retriever = RecentKeyframes(self.keyframes) if retriever is None else retriever
         self.tsdf_manager = None
         if tsdf_global_cfg is not None and tsdf_global_cfg.get("enabled", False):   # main.py:78-88
@@ -96,6 +97,14 @@ class SlamSystem:
 
             self.tsdf_manager = TSDFGlobalManager(self.keyframes, tsdf_global_cfg, config.get("use_calib", False), device)
             self.tsdf_manager.start()
+        # the camera-side half of the dual TSDF (main.py:253-287): local block refinement of keyframes that left the
+        # sliding window; scheduled and processed by the backend task (synchronous form of the refiner thread)
+        self.tsdf_refiner = None
+        if tsdf_refine_cfg is not None and tsdf_refine_cfg.get("enabled", False):
+            from mast3r_slam.tsdf_refine import TSDFRefiner
+
+            self.tsdf_refiner = TSDFRefiner(tsdf_refine_cfg, self.keyframes, quality_service, device)
+            self.tsdf_refiner.start()
         assert backend in ("inline", "thread")
         self._lock = threading.RLock()
         self._hand = {"main": None, "backend": None}   # event at the end of each side's last critical section
@@ -108,14 +117,30 @@ class SlamSystem:
         self.stats = dict(frames=0, keyframes=0, group_calls=0, decoded_rows=0, void_rows=0, relocalised=0)
 
     # ------------------------------------------------------------------ frontend (main.py:325-446)
-    def run(self, frames):
-        """Track a sequence of Frame objects (frame.create_frame) in order; returns the per-frame results of step()."""
+    def run(self, frames, start=0, stop=None, release=False):
+        """Track frames[start:stop] (Frame objects, frame.create_frame) in order; returns the per-frame results of
+        step().  A sequence may be fed in several calls over the SAME list (the look-ahead state carries over).
+        `release` drops the list's reference to a frame once it has been tracked (keyframes live on in the store), so
+        that a long sequence does not keep every pointmap alive."""
         out = []
-        for i in range(len(frames)):
+        stop = len(frames) if stop is None else min(stop, len(frames))
+        self._enc_hi = max(self._enc_hi, start)
+        for i in range(start, stop):
             if self.frame_group > 1:
-                self._look_ahead(frames, i)
+                self._look_ahead(frames, i, stop)
             out.append(self.step(frames[i]))
+            if release:
+                frames[i] = None
         return out
+
+    def finish(self):
+        """End of the sequence (main.py:449-560): drain the backend, then the local refiner's final pass over the
+        keyframes still inside its window."""
+        self.drain()
+        if self.tsdf_refiner is not None and len(self.keyframes) > 0:
+            with self._critical("main"):
+                self.tsdf_refiner.schedule_final_pass(len(self.keyframes) - 1)
+                self.tsdf_refiner.process_queue()
 
     def step(self, frame):
         """One iteration of the main loop for an already created frame -> dict(mode, new_kf, try_reloc, pose) with
@@ -206,8 +231,8 @@ class SlamSystem:
             frame.pos.record_stream(main)
             frame.enc_event = None
 
-    def _look_ahead(self, frames, i):
-        B, n = self.frame_group, len(frames)
+    def _look_ahead(self, frames, i, stop=None):
+        B, n = self.frame_group, (len(frames) if stop is None else stop)
         main = torch.cuda.current_stream(self.device)
         while self._enc_hi < min(n, i + 2 * B):          # encoder: groups of B, up to two groups ahead of frame i
             grp = [frames[k] for k in range(self._enc_hi, min(n, self._enc_hi + B))]
@@ -255,6 +280,10 @@ class SlamSystem:
             self._solve()
             if self.tsdf_manager is not None:
                 self.tsdf_manager.on_after_backend_solve(self.factor_graph)
+            if self.tsdf_refiner is not None:      # main.py:403-421, after the backend task of the keyframe
+                self.tsdf_refiner.registry.tick()
+                self.tsdf_refiner.maybe_schedule_sliding_window(idx)
+                self.stats["refine_blocks"] = self.stats.get("refine_blocks", 0) + self.tsdf_refiner.process_queue()
 
     def _solve(self):
         if config["use_calib"]:

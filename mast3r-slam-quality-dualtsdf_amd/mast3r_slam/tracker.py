@@ -1,13 +1,14 @@
 """Mirror of mast3r_slam/tracker.py (FrameTracker, lines 15-317): same class, method names and return
 values.  Inference + matching + the whole <=50-iteration Sim3 Gauss-Newton run in libmslam_hip.so; the
-quality-service submission (tracker.py:94-145) is out of scope."""
+quality-service submission (tracker.py:94-145) happens when a `quality_service` is attached (main.py:246), with
+device tensors in the job instead of numpy copies."""
 import numpy as np
 import torch
 
 import mslam_hip as _m
 from lietorch_hip import Sim3
 from mast3r_slam.config import config
-from mast3r_slam.geometry import constrain_points_to_ray
+from mast3r_slam.geometry import act_Sim3, constrain_points_to_ray, point_to_ray_dist
 from mast3r_slam.mast3r_utils import mast3r_match_asymmetric
 
 
@@ -20,6 +21,7 @@ class FrameTracker:
         self.reset_idx_f2k()
         self._ws = None
         self._status = None
+        self.quality_service = None
 
     def reset_idx_f2k(self):
         self.idx_f2k = None
@@ -59,6 +61,18 @@ class FrameTracker:
                                                          valid_meas_k, K, img_size)
         if not ok:  # "Cholesky failed" (tracker.py:91-93)
             return False, [], True
+
+        if self.quality_service is not None and not use_calib:   # tracker.py:94-145 (ray-distance residual form)
+            Xf_g = Xf[idx_f2k]                                    # the reference's Xf is the gathered one (:181-206)
+            rd_k = point_to_ray_dist(Xk, jacobian=False)
+            rd_f = point_to_ray_dist(act_Sim3(T_CkCf, Xf_g, jacobian=False), jacobian=False)
+            vec = T_CkCf.data.view(-1, 8)
+            w = vec[..., 6].clamp(-1.0, 1.0).abs()
+            self.quality_service.submit({
+                "kf_id": int(len(self.keyframes) - 1), "frame_id": int(keyframe.frame_id), "H": int(img_size[0]),
+                "W": int(img_size[1]), "valid_kf": valid_kf.view(-1), "r_pix": torch.linalg.norm(rd_k - rd_f, dim=1),
+                "Ck": Ck.view(-1), "Qk": Qk.view(-1), "t_norm": vec[..., :3].norm(dim=-1).mean(),
+                "theta": (2.0 * torch.arccos(w)).mean()})
 
         frame.T_WC = T_WCf
         Xkk = T_CkCf.act(Xkf)

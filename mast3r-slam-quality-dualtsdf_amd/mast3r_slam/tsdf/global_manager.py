@@ -2,7 +2,16 @@
 (lines 177-226), same constructor signatures and method names.  The reference runs the integrator and the pose
 optimiser as daemon threads that poll every 0.1 s; here one synchronous pass of each runs inside
 `on_after_backend_solve` on the caller's stream (bench.py / SlamSystem call it from the backend), so the order
-integrate-new -> re-integrate-updated -> optimise is fixed instead of depending on thread timing."""
+integrate-new -> re-integrate-updated -> optimise is fixed instead of depending on thread timing.
+
+Budgets.  In the reference the work a backend solve queues (re-fuse EVERY optimised keyframe, refine EVERY optimised
+pose) is drained by the two threads at whatever rate they manage: the optimiser thread takes `max_opt_batch` (1)
+keyframe per 0.15 s cycle (global_manager.py:131-160), the integrator what its thread time allows, both queues are
+bounded (256) with de-duplication and whatever is still queued at shutdown is dropped (join timeout 2 s).  The
+synchronous form keeps the queues (FIFO, de-duplicated, bounded) and spends a bounded budget per backend solve:
+`sync_reintegrate_per_solve` re-fusions and `sync_optimize_per_solve` pose refinements (default 4 each; 0 = drain
+completely), so the cost of a solve does not grow with the number of keyframes while every keyframe is still
+revisited in turn."""
 import torch
 
 from lietorch_hip import Sim3
@@ -31,12 +40,15 @@ class TSDFGlobalIntegrator:
                 break
             self.pending.append(idx)
 
-    def _process_dirty_queue(self):
-        """global_manager.py:71-79: keyframes whose pose the backend moved are fused again at the new pose."""
-        while self.pending:
+    def _process_dirty_queue(self, budget=0):
+        """global_manager.py:71-79: keyframes whose pose the backend moved are fused again at the new pose
+        (`budget` > 0: at most that many per call, the rest stay queued)."""
+        done = 0
+        while self.pending and (budget <= 0 or done < budget):
             idx = self.pending.pop(0)
             if idx < len(self.keyframes):
                 self._integrate_single(idx)
+                done += 1
 
     def run_once(self):
         """One pass of the reference thread's loop body (global_manager.py:57-60)."""
@@ -76,6 +88,7 @@ class TSDFGlobalManager:
 
     def __init__(self, keyframes, cfg, use_calib, device):
         from .global_volume import TSDFVolume
+
         from .tsdf_optimizer import TSDFPoseOptimizer
 
         self.enabled = bool(cfg.get("enabled", False))
@@ -86,17 +99,33 @@ class TSDFGlobalManager:
                                  capacity=int(cfg.get("hash_capacity", 1 << 22)), device=device)
         self.optimizer = TSDFPoseOptimizer(self.volume, keyframes, cfg, use_calib, device)
         self.integrator = TSDFGlobalIntegrator(self.volume, keyframes, cfg, self.optimizer)
+        self.reintegrate_budget = int(cfg.get("sync_reintegrate_per_solve", 4))
+        self.optimize_budget = int(cfg.get("sync_optimize_per_solve", 4))
+        self.max_opt_pending = int(cfg.get("opt_queue", cfg.get("reintegration_queue", 256)))
+        self.opt_pending = []     # TSDFGlobalOptThread.queue + pending (global_manager.py:121-143)
 
     def start(self):
         pass
 
+    def _maintain(self):
+        """One small D2H read per solve, BEFORE its work: samples dropped by the previous solve raise; the table grows so
+        that everything this solve may insert (the not yet fused keyframes + the re-fusion budget, every in-band sample
+        a new voxel) still leaves it half empty - the table cannot grow in the middle of an integrate."""
+        v = self.volume
+        band = int(2.0 * v.truncation / (0.5 * v.voxel_size)) + 4
+        n_new = max(0, len(self.keyframes) - self.integrator.next_idx)
+        n_re = self.reintegrate_budget if self.reintegrate_budget > 0 else self.integrator.max_pending
+        self.volume.maintain(reserve=(n_new + n_re) * self.integrator.max_points * band)
+
     def shutdown(self):
-        pass
+        if self.enabled:
+            self.volume.maintain()   # samples dropped by the last solve are reported here
 
     def on_after_backend_solve(self, factor_graph):
         """global_manager.py:213-226, followed by the pass the reference's two threads would make."""
         if not self.enabled:
             return
+        self._maintain()
         self.integrator._integrate_new_keyframes()
         idx_tensor = getattr(factor_graph, "last_unique_kf_idx", None)
         if idx_tensor is None:
@@ -106,5 +135,10 @@ class TSDFGlobalManager:
         if not indices:
             return
         self.integrator.mark_pose_update(indices)
-        self.integrator._process_dirty_queue()
-        self.optimizer.optimize_keyframes(indices, context="factor")
+        self.integrator._process_dirty_queue(self.reintegrate_budget)
+        for i in indices:      # TSDFGlobalOptThread.enqueue
+            if i not in self.opt_pending and len(self.opt_pending) < self.max_opt_pending:
+                self.opt_pending.append(i)
+        n = len(self.opt_pending) if self.optimize_budget <= 0 else min(self.optimize_budget, len(self.opt_pending))
+        batch, self.opt_pending = self.opt_pending[:n], self.opt_pending[n:]
+        self.optimizer.optimize_keyframes(batch, context="factor")

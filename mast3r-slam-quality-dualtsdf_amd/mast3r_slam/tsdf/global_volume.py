@@ -65,6 +65,30 @@ class TSDFVolume:
                  "tsdf_header")
         return out
 
+    def maintain(self, max_load=0.5, reserve=0):
+        """The reference's dict never fills up; the table does.  One small D2H read (stream sync): raises if samples
+        were dropped (table full / coordinate out of the 21-bit key range) and doubles + rehashes the table when more
+        than `max_load` of the slots would be taken after `reserve` further insertions (the caller's bound on what it
+        integrates before the next call: the table cannot grow in the middle of an integrate).  The synchronous
+        pipeline calls it once per backend solve (TSDFGlobalManager.on_after_backend_solve).  Returns (voxels, capacity)."""
+        h = self._header()
+        if h[1]:
+            raise RuntimeError(f"TSDFVolume: samples were dropped (overflow code {int(h[1])}, {int(h[0])} voxels in "
+                               f"{self.capacity} slots); raise tsdf_global.hash_capacity")
+        while int(h[0]) + int(reserve) > max_load * self.capacity:
+            L = _m.lib()
+            new_cap = self.capacity * 2
+            nbytes = L.mslam_tsdf_table_bytes(new_cap)
+            new = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _m.check(L.mslam_tsdf_table_init(_m.ptr(new), nbytes, new_cap, _m.stream_ptr()), "tsdf_table_init")
+            _m.check(L.mslam_tsdf_rehash(_m.ptr(self._table), self.capacity, _m.ptr(new), new_cap, _m.stream_ptr()),
+                     "tsdf_rehash")
+            self._table, self.capacity = new, new_cap
+            h = self._header()
+            if h[1]:
+                raise RuntimeError("TSDFVolume: rehash overflow")
+        return int(h[0]), self.capacity
+
     # ------------------------------------------------------------------
     def integrate(self, points_world, confidences, cam_origin, step_scale=0.5, return_fused=True):
         """global_volume.py:35-72.  Returns the number of fused points (needs one stream sync; pass

@@ -49,7 +49,9 @@ class TSDFPoseOptimizer:
         count = min(max_samples, valid_idx.numel())
         choice = valid_idx[torch.randperm(valid_idx.numel(), device=valid_idx.device)[:count]]
         pose = self.refine_pose(Sim3(frame.T_WC.data.clone()), points[choice], conf[choice], iterations=iterations)
-        frame.T_WC = pose
+        # write back THROUGH the store (tsdf_optimizer.py:88-92 assigns keyframes.T_WC[idx] under the lock): with the
+        # SharedKeyframes buffers `frame` is a temporary of views and rebinding its attribute would be lost
+        self.keyframes.update_T_WCs(pose, torch.tensor([idx]))
 
     def normal_equations(self, points_world, conf):
         """_build_linear_system + _accumulate_system (tsdf_optimizer.py:94-116) for world points:

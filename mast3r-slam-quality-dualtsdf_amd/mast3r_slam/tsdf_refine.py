@@ -1,10 +1,16 @@
-"""Mirror of the compute part of mast3r_slam/tsdf_refine.py (TSDFRefiner): local dense-block TSDF build,
-ray-cast surface extraction and the block refinement decision (lines 667-1064), same method names and
-config keys.  The two python double loops run as HIP kernels (csrc/tsdf_local.hip).  The thread, queue,
-retry registry and quality-service plumbing of the reference class (lines 33-665) are out of scope
-("scheduling/threads OUT OF SCOPE"); `refine_block` below is called synchronously."""
+"""Mirror of mast3r_slam/tsdf_refine.py (TSDFRefiner): local dense-block TSDF build, ray-cast surface extraction and
+the block refinement decision (lines 667-1064), block selection / clustering (lines 431-601) and the sliding-window
+scheduling surface main.py drives (lines 246-429: `.start/.queue/.stats/.stop_flag/.registry/
+.maybe_schedule_sliding_window/.schedule_final_pass`), same method names and config keys.  The two python double
+loops run as HIP kernels (csrc/tsdf_local.hip).  The reference class is a daemon thread that drains `.queue`; here the
+same loop body is `process_queue()`, called synchronously by the owner (SlamSystem's backend) - no thread, no sleeps,
+no time-based retry back-off (a deferred keyframe is retried at the next call)."""
 import dataclasses
+import math
+import queue
+import threading
 
+import numpy as np
 import torch
 
 import mslam_hip as _m
@@ -22,6 +28,72 @@ class PatchBlock:
     depth_variance: float = 0.0
 
 
+@dataclasses.dataclass(frozen=True)
+class BlockKey:
+    kf_id: int
+    block_id: int
+
+
+class RefineRegistry:
+    """tsdf_refine.py:50-137: per-block state machine (IDLE -> QUEUED -> RUNNING -> COOLDOWN) and history."""
+    IDLE, QUEUED, RUNNING, COOLDOWN = 0, 1, 2, 3
+
+    def __init__(self, cfg):
+        self.lock = threading.Lock()
+        self.state, self.history = {}, {}
+        self.cooldown_frames = cfg["cooldown_frames"]
+        self.frame_count = 0
+        self.success_rate = 0.0
+
+    def tick(self):
+        with self.lock:
+            self.frame_count += 1
+
+    def get_stats(self):
+        with self.lock:
+            attempts = sum(h.get("attempts", 0) for h in self.history.values())
+            successes = sum(h.get("successes", 0) for h in self.history.values())
+            return {"active_blocks": len([k for k, s in self.state.items() if s != self.IDLE]),
+                    "total_attempts": attempts, "success_rate": successes / max(1, attempts),
+                    "frame_count": self.frame_count}
+
+    def try_enqueue(self, key):
+        with self.lock:
+            if self.state.get(key, self.IDLE) != self.IDLE:
+                return False
+            self.state[key] = self.QUEUED
+            return True
+
+    def begin_run(self, key):
+        with self.lock:
+            if self.state.get(key) != self.QUEUED:
+                return False
+            self.state[key] = self.RUNNING
+            return True
+
+    def finish_run(self, key, success, gain):
+        with self.lock:
+            hist = self.history.setdefault(key, {"attempts": 0, "successes": 0, "last_gain": 0.0, "best_gain": 0.0})
+            hist["attempts"] += 1
+            if success:
+                hist["successes"] += 1
+            hist["last_gain"] = gain
+            hist["best_gain"] = max(hist["best_gain"], gain)
+            hist["last_frame"] = self.frame_count
+            self.state[key] = self.COOLDOWN
+            attempts = sum(h.get("attempts", 0) for h in self.history.values())
+            successes = sum(h.get("successes", 0) for h in self.history.values())
+            self.success_rate = successes / max(1, attempts)
+
+    def cooldown_expired(self, key):
+        with self.lock:
+            hist = self.history.get(key)
+            if hist and self.frame_count - hist["last_frame"] > self.cooldown_frames:
+                self.state[key] = self.IDLE
+                return True
+            return False
+
+
 class TSDFRefiner:
     def __init__(self, cfg=None, shared_keyframes=None, quality_service=None, device="cuda"):
         self.cfg = dict(config["tsdf_refine"]) if cfg is None else dict(cfg)
@@ -30,11 +102,228 @@ class TSDFRefiner:
                 raise ValueError(f"Missing required TSDF config parameter: {k}")   # tsdf_refine.py:146-150
         self.device = torch.device(device)
         self.keyframes = shared_keyframes
+        self.quality_service = quality_service
         self.versions = {}
         self._ws = None
-        self.stats = {"total_blocks": 0, "successful_blocks": 0,
+        self.registry = RefineRegistry({"cooldown_frames": int(self.cfg.get("cooldown_frames", 35))})
+        self.queue = queue.Queue(maxsize=int(self.cfg.get("max_pending_tasks", 50)))
+        self.stop_flag = threading.Event()
+        self._pending_map = {}
+        self.stats = {"total_blocks": 0, "successful_blocks": 0, "total_processing_time": 0.0,
                       "debug_info": {"tsdf_constructions": 0, "surface_extractions": 0, "displacement_rejects": 0,
                                      "hit_ratio_rejects": 0}}
+
+    # ------------------------------------------------------------------ thread surface of the reference class
+    def start(self):
+        """The reference starts the worker thread here (main.py:277); the synchronous form has nothing to start."""
+
+    def is_alive(self):
+        return not self.stop_flag.is_set()
+
+    def join(self, timeout=None):
+        self.process_queue()
+
+    # ------------------------------------------------------------------ scheduling (tsdf_refine.py:246-429)
+    def schedule_final_pass(self, final_kf_id):
+        """tsdf_refine.py:246-258 (the 1 s sleep between the two passes only waits for the worker thread)."""
+        self.maybe_schedule_sliding_window(final_kf_id, is_final_pass=True)
+        self.maybe_schedule_sliding_window(final_kf_id, is_final_pass=True)
+
+    def maybe_schedule_sliding_window(self, current_kf_id, is_final_pass=False):
+        """tsdf_refine.py:260-346: keyframe current - window_size is scheduled once it leaves the window; a keyframe
+        that could not be scheduled is retried (<= max_retry_attempts_per_kf) at later calls; the final pass
+        schedules the keyframes still inside the window.  Retry order: fewest attempts first."""
+        if not self.cfg["enabled"]:
+            return
+        window = int(self.cfg.get("window_size", 3))
+        retry_slack = int(self.cfg.get("retry_slack_frames", 2))
+        max_pending = int(self.cfg.get("max_pending_kf", 64))
+        max_attempts = int(self.cfg.get("max_retry_attempts_per_kf", 3))
+        min_keep_id = max(0, current_kf_id - window - retry_slack)
+        for k in [k for k in self._pending_map if k < min_keep_id]:
+            self._pending_map.pop(k, None)
+        if is_final_pass:
+            for kf_id in range(max(0, current_kf_id - window + 1), current_kf_id + 1):
+                if kf_id in self._pending_map:
+                    continue
+                if not self._schedule_refinement(kf_id):
+                    self._pending_map[kf_id] = {"attempts": 1, "final_pass": True}
+            return
+        due = [(k, v) for k, v in self._pending_map.items() if k >= min_keep_id and not v.get("final_pass", False)]
+        if current_kf_id >= window:
+            target = current_kf_id - window
+            if not self._schedule_refinement(target):
+                ent = self._pending_map.get(target, {"attempts": 0})
+                ent["attempts"] += 1
+                if ent["attempts"] <= max_attempts:
+                    self._pending_map[target] = ent
+                else:
+                    self._pending_map.pop(target, None)
+        due.sort(key=lambda x: (x[1].get("attempts", 0), -x[1].get("best_gain", 0.0)))
+        for k, ent in due[:3]:
+            if self._schedule_refinement(k):
+                self._pending_map.pop(k, None)
+            else:
+                ent["attempts"] += 1
+                if ent["attempts"] <= max_attempts:
+                    self._pending_map[k] = ent
+                else:
+                    self._pending_map.pop(k, None)
+        if len(self._pending_map) > max_pending:
+            for k in sorted(self._pending_map.keys())[:len(self._pending_map) - max_pending]:
+                self._pending_map.pop(k, None)
+
+    def _schedule_refinement(self, kf_id):
+        """tsdf_refine.py:348-429: priority map from the quality service when it has one for the keyframe, else the
+        confidence heuristic (0.05 < C < 0.3 => priority 0.3 - C, normalised); top blocks enqueued."""
+        quality_result = None
+        if self.quality_service is not None and kf_id < len(self.keyframes):
+            quality_result = self.quality_service.get(self.keyframes[kf_id].frame_id)
+        if quality_result is None:
+            if kf_id >= len(self.keyframes):
+                return False
+            kf = self.keyframes[kf_id]
+            H, W = int(kf.img_shape[0, 0]), int(kf.img_shape[0, 1])
+            C = kf.C.reshape(H, W) if kf.C.ndim == 2 else kf.C.reshape(H, W, 1)[..., 0]
+            low_conf_mask = (C < 0.3) & (C > 0.05)
+            if int(low_conf_mask.sum()) < 100:
+                return False
+            priority = (0.3 - C) * low_conf_mask.float()
+            priority = priority / (priority.max() + 1e-8)
+            quality_result = {"priority": priority.cpu(), "patch_size": 16}
+        blocks = self._select_blocks_enhanced(kf_id, quality_result)
+        if len(blocks) == 0:
+            return True
+        blocks.sort(key=lambda b: b.priority, reverse=True)
+        for block in blocks[:int(self.cfg.get("max_rois_per_kf", 3))]:
+            key = BlockKey(block.kf_id, block.block_id)
+            if self.registry.try_enqueue(key):
+                try:
+                    self.queue.put_nowait((key, block))
+                except queue.Full:
+                    break
+        return True
+
+    def _select_blocks_enhanced(self, kf_id, quality_result):
+        """tsdf_refine.py:431-517: top-5 % patches of the priority grid, the max_rois_per_kf best of them, per-patch
+        depth median / variance over pixels with C > 0.05 (> 2 such pixels), then clustering."""
+        priority = quality_result.get("priority")
+        if priority is None:
+            return []
+        if isinstance(priority, np.ndarray):
+            priority = torch.from_numpy(priority)
+        elif isinstance(priority, list):
+            priority = torch.tensor(priority, dtype=torch.float32)
+        patch_size = quality_result.get("patch_size", 16)
+        if priority.ndim != 2:
+            return []
+        Gh, Gw = priority.shape
+        flat_priority = priority.flatten()
+        if flat_priority.numel() == 0:
+            return []
+        threshold = torch.quantile(flat_priority, 0.95)
+        candidate_indices = torch.where(flat_priority >= threshold)[0]
+        K = min(int(self.cfg.get("max_rois_per_kf", 3)), len(candidate_indices))
+        if K == 0:
+            return []
+        topk_values, relative_indices = torch.topk(flat_priority[candidate_indices], k=K)
+        topk_indices = candidate_indices[relative_indices]
+        patch_coords = [(int(idx // Gw), int(idx % Gw)) for idx in topk_indices]
+        patch_priorities = [float(v) for v in topk_values]
+        kf = self.keyframes[min(kf_id, len(self.keyframes) - 1)]
+        H, W = int(kf.img_shape[0, 0]), int(kf.img_shape[0, 1])
+        X_canon = kf.X_canon.reshape(H, W, 3)
+        C = kf.C.reshape(H, W) if kf.C.ndim == 2 else kf.C.reshape(H, W, 1)[..., 0]
+        # one device pass + one D2H read for all K patches (the reference calls .item() twice per patch)
+        stats = []
+        for gh, gw in patch_coords:
+            y0, y1 = gh * patch_size, min((gh + 1) * patch_size, H)
+            x0, x1 = gw * patch_size, min((gw + 1) * patch_size, W)
+            valid_z = X_canon[y0:y1, x0:x1, 2][C[y0:y1, x0:x1] > 0.05]
+            n = valid_z.numel()        # shape of a masked select: the reference syncs here too
+            if n > 2:
+                stats.append(torch.stack((torch.median(valid_z), torch.var(valid_z))))
+            else:
+                stats.append(None)
+        have = [s for s in stats if s is not None]
+        vals = torch.stack(have).cpu().tolist() if have else []
+        valid_coords, valid_depths, valid_variances, valid_priorities = [], [], [], []
+        it = iter(vals)
+        for i, s_ in enumerate(stats):
+            if s_ is None:
+                continue
+            med, var = next(it)
+            valid_coords.append(patch_coords[i]); valid_depths.append(med); valid_variances.append(var)
+            valid_priorities.append(patch_priorities[i])
+        if not valid_coords:
+            return []
+        return self._cluster_patches_enhanced(kf_id, valid_coords, valid_depths, valid_variances, valid_priorities, H, W,
+                                              patch_size)
+
+    def _cluster_patches_enhanced(self, kf_id, patch_coords, patch_depths, patch_variances, patch_priorities, H, W,
+                                  patch_size):
+        """tsdf_refine.py:519-601: greedy 8-connected clustering by depth similarity, <= max_block_edge^2 patches
+        per block, seeds in order of priority."""
+        blocks = []
+        used = [False] * len(patch_coords)
+        block_id = 0
+        z_abs = float(self.cfg.get("z_abs_m", 1e9))
+        z_rel = float(self.cfg.get("z_rel", 1e9))
+        max_edge = int(self.cfg.get("max_block_edge", 1))
+        for seed_idx in sorted(range(len(patch_coords)), key=lambda i: patch_priorities[i], reverse=True):
+            if used[seed_idx] or not math.isfinite(patch_depths[seed_idx]):
+                continue
+            cluster = [seed_idx]
+            used[seed_idx] = True
+            todo = [seed_idx]
+            while todo and len(cluster) < max_edge * max_edge:
+                cur = todo.pop(0)
+                cgh, cgw = patch_coords[cur]
+                for j, (gh2, gw2) in enumerate(patch_coords):
+                    if used[j] or not math.isfinite(patch_depths[j]):
+                        continue
+                    if max(abs(cgh - gh2), abs(cgw - gw2)) > 1:
+                        continue
+                    z1, z2 = patch_depths[cur], patch_depths[j]
+                    depth_diff = abs(z1 - z2)
+                    lo = min(abs(z1), abs(z2))
+                    rel_diff = depth_diff / lo if lo > 0 else float("inf")
+                    if depth_diff <= z_abs or rel_diff <= z_rel:
+                        cluster.append(j)
+                        used[j] = True
+                        todo.append(j)
+            mask2d = torch.zeros((H, W), dtype=torch.bool, device=self.device)
+            for idx in cluster:
+                gh, gw = patch_coords[idx]
+                mask2d[gh * patch_size:min((gh + 1) * patch_size, H), gw * patch_size:min((gw + 1) * patch_size, W)] = True
+            depths = [patch_depths[i] for i in cluster if math.isfinite(patch_depths[i])]
+            blocks.append(PatchBlock(kf_id=kf_id, block_id=block_id, patch_indices=[patch_coords[i] for i in cluster],
+                                     pixel_mask=mask2d.reshape(-1),
+                                     depth_median=float(np.median(depths)),
+                                     priority=float(np.mean([patch_priorities[i] for i in cluster])),
+                                     depth_variance=float(np.var(depths))))
+            block_id += 1
+        return blocks
+
+    def process_queue(self, max_blocks=None):
+        """The body of the reference's worker loop (tsdf_refine.py:603-640) for the queued blocks; returns the number
+        of blocks processed."""
+        done = 0
+        while (max_blocks is None or done < max_blocks) and not self.queue.empty():
+            key, block = self.queue.get_nowait()
+            if not self.registry.begin_run(key):
+                continue
+            try:
+                success, gain = self._refine_block_enhanced(block)
+            except Exception as e:   # the reference prints and counts the block as failed (:627-631)
+                print(f"[TSDF-ERROR] Refinement error for block {key.block_id}: {e}")
+                success, gain = False, 0.0
+            self.stats["total_blocks"] += 1
+            if success:
+                self.stats["successful_blocks"] += 1
+            self.registry.finish_run(key, success, gain)
+            done += 1
+        return done
 
     # ------------------------------------------------------------------
     def _grid_dims(self, xyz_min, xyz_max):

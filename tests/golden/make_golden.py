@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block  evaluate  dataloader
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block  refine_schedule  evaluate  dataloader
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -1005,6 +1005,123 @@ def json_dumps(o):
 SECTIONS["dataloader"] = section_dataloader
 SECTIONS["evaluate"] = section_evaluate
 SECTIONS["refine_block"] = section_refine_block
+
+
+def section_refine_schedule():
+    """TSDFRefiner block selection and sliding-window scheduling (tsdf_refine.py:246-601) of the reference class itself
+    (never started as a thread) on a store of 9 small keyframes: `_select_blocks_enhanced` on a seeded priority grid
+    (with clustering on and off), `_schedule_refinement`'s confidence fallback, and the queue after every
+    `maybe_schedule_sliding_window(k)` of a run plus `schedule_final_pass` (time.sleep stubbed)."""
+    import contextlib
+    import io
+    import threading
+    import time as _time
+
+    from mast3r_slam import synthetic
+
+    tr = load_by_path("ref_tsdf_refine_rs", f"{REF}/mast3r_slam/tsdf_refine.py")
+    base = dict(enabled=True, window_size=5, voxel_size=0.02, trunc_dist=0.08, max_grid_dim=64, roi_size=0.4, ray_samples=64,
+                max_displacement=0.015, min_weight_threshold=0.01, confidence_boost=0.08, confidence_max=1.3, min_hit_rate=0.05,
+                max_rois_per_kf=3, min_confidence=0.2, max_pending_tasks=50)
+    H, W, NKF = 96, 128, 9
+    rng = np.random.default_rng(12)
+    Xs, Cs = [], []
+    for k in range(NKF):
+        X = synthetic.render_pointmap(synthetic.camera_pose(5 * k), H, W).reshape(-1, 3).astype(np.float32)
+        C = rng.uniform(0.35, 1.2, (H * W, 1)).astype(np.float32)
+        lo = rng.uniform(0.06, 0.29, (H, W)).astype(np.float32)
+        C2 = C.reshape(H, W).copy()
+        if k != 3:                                            # keyframe 3 has no low-confidence region: scheduling fails
+            y0, x0 = 16 * (k % 4), 16 * (k % 6)
+            C2[y0:y0 + 32, x0:x0 + 48] = lo[y0:y0 + 32, x0:x0 + 48]
+        C2[40:44, :] = 0.01
+        if k in (2, 5):      # the fallback map is per PIXEL but read with patch_size 16 (tsdf_refine.py:381-392, 437-470):
+            C2[0:3, 0:4] = rng.uniform(0.06, 0.08, (3, 4))     # only pixels (y < H/16, x < W/16) can name a valid patch
+        Xs.append(X); Cs.append(C2.reshape(-1, 1))
+    out = dict(H=H, W=W, X=np.stack(Xs), C=np.stack(Cs))
+
+    class KF:
+        pass
+
+    kfs = []
+    for k in range(NKF):
+        kf = KF()
+        kf.frame_id = 10 * k; kf.img_shape = torch.tensor([[H, W]])
+        kf.X_canon = torch.from_numpy(Xs[k].copy()); kf.C = torch.from_numpy(Cs[k].copy())
+        kfs.append(kf)
+
+    class Store:
+        lock = threading.RLock()
+
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return kfs[i]
+
+    def dump_blocks(prefix, blocks):
+        out[prefix + "_n"] = np.array(len(blocks))
+        for b_i, b in enumerate(blocks):
+            out[f"{prefix}_{b_i}_ids"] = np.array([b.kf_id, b.block_id])
+            out[f"{prefix}_{b_i}_patches"] = np.array(b.patch_indices, np.int64).reshape(-1, 2)
+            out[f"{prefix}_{b_i}_mask"] = np.flatnonzero(b.pixel_mask.numpy())
+            out[f"{prefix}_{b_i}_vals"] = np.array([b.depth_median, b.priority, b.depth_variance])
+
+    prio = rng.uniform(0, 1, (H // 16, W // 16)).astype(np.float32)
+    prio[2, 3], prio[2, 4], prio[3, 4] = 0.99, 0.98, 0.97      # three adjacent top patches
+    out["priority"] = prio
+    real_sleep = _time.sleep
+    tr.time.sleep = lambda s: None
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            for name, over in (("select_single", {}), ("select_cluster", dict(max_block_edge=2, z_rel=0.5))):
+                ref = tr.TSDFRefiner(dict(base, **over), Store(NKF), None, "cpu")
+                dump_blocks(name, ref._select_blocks_enhanced(4, {"priority": torch.from_numpy(prio), "patch_size": 16}))
+            ref = tr.TSDFRefiner(dict(base), Store(NKF), None, "cpu")
+            ok = ref._schedule_refinement(2)
+            items = list(ref.queue.queue)
+            out["fallback_ok"] = np.array(ok)
+            dump_blocks("fallback", [b for _, b in items])
+            out["fallback_fail_ok"] = np.array(ref._schedule_refinement(3))
+            ok5 = ref._schedule_refinement(5)
+            out["fallback5_ok"] = np.array(ok5)
+            dump_blocks("fallback5", [b for _, b in list(ref.queue.queue)[len(items):]])
+
+            class FakeQuality:     # AsynchronousQualityService surface used by the refiner: get(frame_id), poll()
+                def get(self, frame_id):
+                    if frame_id == 30:
+                        return None          # keyframe 3: no result yet -> confidence fallback -> fails -> retried
+                    g = np.random.default_rng(frame_id).uniform(0, 1, (H // 16, W // 16)).astype(np.float32)
+                    return {"priority": g, "patch_size": 16, "kf_id": frame_id}
+
+                def poll(self):
+                    pass
+
+            out["quality_grids"] = np.stack([np.random.default_rng(10 * k).uniform(0, 1, (H // 16, W // 16)).astype(np.float32)
+                                             for k in range(NKF)])
+            # a run: keyframes arrive one by one (the store grows), then the final pass
+            store = Store(0)
+            ref = tr.TSDFRefiner(dict(base), store, FakeQuality(), "cpu")
+            trace = []
+            for cur in range(NKF):
+                store.n = cur + 1
+                ref.maybe_schedule_sliding_window(cur)
+                trace.append([[k.kf_id, k.block_id] for k, _ in ref.queue.queue])
+            ref.schedule_final_pass(NKF - 1)
+            trace.append([[k.kf_id, k.block_id] for k, _ in ref.queue.queue])
+    finally:
+        tr.time.sleep = real_sleep
+    for i, t in enumerate(trace):
+        out[f"trace_{i}"] = np.array(t, np.int64).reshape(-1, 2)
+    out["trace_n"] = np.array(len(trace))
+    print("refine_schedule", {k: (v.tolist() if v.size < 24 else v.shape) for k, v in out.items() if k.startswith(("trace", "select_single_0", "fallback_ok", "fallback_n", "fallback_fail", "fallback5_n", "fallback5_0_p"))})
+    np.savez_compressed(os.path.join(HERE, "refine_schedule.npz"), **out, **meta())
+
+
+SECTIONS["refine_schedule"] = section_refine_schedule
 SECTIONS["utils_wrappers"] = section_utils_wrappers
 SECTIONS["track_logic"] = section_track_logic
 SECTIONS["factor_graph"] = section_factor_graph
