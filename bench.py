@@ -75,6 +75,9 @@ def parse():
                     help="run the keyframe backend inline in the tracking loop (the reference's single_thread mode)")
     ap.add_argument("--frame-group", type=int, default=4,
                     help="frames whose network stages run in one batch call (SlamSystem frame groups)")
+    ap.add_argument("--decode-ahead", type=int, default=0,
+                    help="SlamSystem decode_ahead: issue the next group's pair decode on its own stream when at most this "
+                         "many decoded frames are left (0: on the tracking stream when none is left)")
     ap.add_argument("--no-tsdf", action="store_true", help="debug: global + local TSDF off")
     ap.add_argument("--no-network", action="store_true", help="debug: geometry stand-in only, no network launches")
     ap.add_argument("--depth-scale", type=float, default=1.0, help="debug: <1 shrinks the encoder depth")
@@ -146,7 +149,7 @@ class Session:
             tr = dict(config["tsdf_refine"], enabled=True)
             qs = SynchronousQualityService(device=dev, lookup_both=True)
         self.system = SlamSystem(self.model, dev, retriever=retriever, frame_group=max(1, args.frame_group),
-                                 tsdf_global_cfg=tg, tsdf_refine_cfg=tr, quality_service=qs,
+                                 tsdf_global_cfg=tg, tsdf_refine_cfg=tr, quality_service=qs, decode_ahead=args.decode_ahead,
                                  backend="inline" if args.no_backend_thread else "thread")
         # the stream: RGB frames rendered on the device, resident in HBM before the clock starts
         shp = torch.tensor([[H, W]])
@@ -306,9 +309,20 @@ def main():
     rows0 = (ses.model.enc_rows, ses.model.dec_rows)
     M, N, K = dominant_shape(B)
     mslam_hip.check(L.mslam_gemm_profile_begin(M, N, K, 8192), "gemm_profile_begin")
+    prof = None
+    if os.environ.get("BENCH_CPROFILE"):   # debug: where the frontend thread's host time goes
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     ses.run(args.steps)
-    t_enqueued = time.perf_counter() - t0   # host time of the frontend loop (it reads one tracking verdict per frame)
+    t_enqueued = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)   # host time of the frontend loop (it reads one tracking verdict per frame)
     ses.drain()                             # every queued keyframe task has been issued ...
     barrier(world)                          # ... and (device-wide synchronise inside) has finished
     elapsed = time.perf_counter() - t0

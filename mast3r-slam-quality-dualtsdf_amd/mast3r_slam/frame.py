@@ -139,8 +139,9 @@ class KeyframeStore:
         return self._kfs[-1] if self._kfs else None
 
     def update_T_WCs(self, T_WCs, idx):
-        for k, i in enumerate(idx.tolist() if hasattr(idx, "tolist") else idx):
-            self._kfs[int(i)].T_WC = Sim3(T_WCs.data[k].reshape(1, 8).clone())
+        data = T_WCs.data.reshape(-1, 8).clone()      # one copy; every keyframe gets a view of it (poses are never
+        for k, i in enumerate(idx.tolist() if hasattr(idx, "tolist") else idx):   # written in place)
+            self._kfs[int(i)].T_WC = Sim3(data[k].reshape(1, 8))
 
 
 class _Value:

@@ -2,10 +2,15 @@
 matching per edge batch, two-way edge preparation and the calls into the native Gauss-Newton.
 
 Multi-GPU (new; the reference is single-device): when torch.distributed is initialised and
-`shard_edges=True`, each rank accumulates the normal-equation blocks of ITS slice of the directed edges,
-the reference-layout block buffers Hs[4,E,7,7] / gs[2,E,7] are summed with ONE all-reduce per GN
-iteration (RCCL over xGMI on MI355X; other ranks' slots are zero so the sum is exact and every rank
-gets bit-identical blocks), and every rank runs the same fp64 solve + retraction - no broadcast."""
+`shard_edges=True`, the ranks hold the same keyframes (replicated; `broadcast_keyframe` ships a new keyframe's
+encoder tokens, 3.1 MB, from the rank that tracked it) and share the backend of ONE session:
+* add_factors: each rank decodes + matches ITS slice of the new keyframe pairs (the reference loops over them
+  serially, mast3r_utils.py:83-115); the match results (idx, valid, Q: ~2.5 MB per pair direction) are
+  all-gathered, so every rank appends the same edges;
+* solve: each rank accumulates the normal-equation blocks of ITS slice of the directed edges, the reference-layout
+  block buffers Hs[4,E,7,7] / gs[2,E,7] are summed with ONE all-reduce per GN iteration (RCCL over xGMI on MI355X;
+  other ranks' slots are zero so the sum is exact and every rank gets bit-identical blocks), and every rank runs the
+  same fp64 solve + retraction - no broadcast."""
 import torch
 
 import mast3r_slam_backends
@@ -43,7 +48,10 @@ class FactorGraph:
         pos_j = torch.cat([kf.pos for kf in kf_jj])
         shape_i = [kf.img_true_shape for kf in kf_ii]
         shape_j = [kf.img_true_shape for kf in kf_jj]
-        res = mast3r_match_symmetric(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
+        if self.shard_edges and torch.distributed.is_available() and torch.distributed.is_initialized():
+            res = match_symmetric_sharded(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
+        else:
+            res = mast3r_match_symmetric(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
         return self.add_matched_factors(ii, jj, *res, min_match_frac=min_match_frac, is_reloc=is_reloc)
 
     def add_matched_factors(self, ii, jj, idx_i2j, idx_j2i, valid_match_j, valid_match_i, Qii, Qjj, Qji, Qij,
@@ -96,15 +104,17 @@ class FactorGraph:
         return Xs, T_WCs, Cs
 
     # ------------------------------------------------------------------
-    def _solve(self, kind):
+    # The solve in three phases so that a threaded owner (SlamSystem backend="thread") can hold its hand-over lock
+    # only around the two short ones: prepare() READS the keyframe store (copies: stack / contiguous), run() works
+    # on those copies alone, commit() WRITES the optimised poses back (global_opt.py:145-164 does all three in line).
+    def prepare_solve(self, kind):
         pin = self.cfg["pin"]
         unique_kf_idx = self.get_unique_kf_idx()
         if unique_kf_idx.numel() <= pin:
             self.last_unique_kf_idx = None
-            return
+            return None
         Xs, T_WCs, Cs = self.get_poses_points(unique_kf_idx)
         self.last_unique_kf_idx = unique_kf_idx.detach().cpu()
-        c = self.cfg
         K = self.K
         height = width = 0
         if kind == "calib":
@@ -112,20 +122,39 @@ class FactorGraph:
             Xs = constrain_points_to_ray(img_size, Xs, K)
             height, width = int(img_size[0]), int(img_size[1])
         ii, jj, idx_ii2jj, valid_match, Q = self.prep_two_way_edges()
-        pose_data = T_WCs.data[:, 0, :].contiguous()
-        Xs, Cs = Xs.contiguous(), Cs.contiguous()
+        return dict(kind=kind, pin=pin, unique_kf_idx=unique_kf_idx, unique_kf_idx_host=self.last_unique_kf_idx, K=K,
+                    height=height, width=width,
+                    pose_data=T_WCs.data[:, 0, :].contiguous(), Xs=Xs.contiguous(), Cs=Cs.contiguous(),
+                    edges=(ii, jj, idx_ii2jj, valid_match, Q))
+
+    def run_solve(self, job):
+        c, kind, K = self.cfg, job["kind"], job["K"]
+        pose_data, Xs, Cs = job["pose_data"], job["Xs"], job["Cs"]
+        ii, jj, idx_ii2jj, valid_match, Q = job["edges"]
         if self.shard_edges and torch.distributed.is_available() and torch.distributed.is_initialized():
-            gauss_newton_sharded(kind, pose_data, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, c, height, width)
+            gauss_newton_sharded(kind, pose_data, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, c, job["height"],
+                                 job["width"])
         elif kind == "rays":
             mast3r_slam_backends.gauss_newton_rays(
                 pose_data, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, c["sigma_ray"], c["sigma_dist"], c["C_conf"],
                 c["Q_conf"], c["max_iters"], c["delta_norm"])
         else:
             mast3r_slam_backends.gauss_newton_calib(
-                pose_data, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, height, width, c["pixel_border"],
-                c["depth_eps"], c["sigma_pixel"], c["sigma_depth"], c["C_conf"], c["Q_conf"], c["max_iters"],
-                c["delta_norm"])
-        self.frames.update_T_WCs(Sim3(pose_data[:, None, :])[pin:], unique_kf_idx[pin:])
+                pose_data, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, job["height"], job["width"],
+                c["pixel_border"], c["depth_eps"], c["sigma_pixel"], c["sigma_depth"], c["C_conf"], c["Q_conf"],
+                c["max_iters"], c["delta_norm"])
+        job["Xs"] = job["Cs"] = job["edges"] = None     # the copies are no longer needed
+
+    def commit_solve(self, job):
+        pin = job["pin"]
+        # the host copy of the indices (made in prepare_solve): a device tensor would cost a synchronisation here
+        self.frames.update_T_WCs(Sim3(job["pose_data"][:, None, :])[pin:], job["unique_kf_idx_host"][pin:])
+
+    def _solve(self, kind):
+        job = self.prepare_solve(kind)
+        if job is not None:
+            self.run_solve(job)
+            self.commit_solve(job)
 
     def solve_GN_rays(self):
         """global_opt.py:123-164."""
@@ -134,6 +163,55 @@ class FactorGraph:
     def solve_GN_calib(self):
         """global_opt.py:166-223."""
         self._solve("calib")
+
+
+def match_symmetric_sharded(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j, group=None):
+    """mast3r_match_symmetric with the E keyframe pairs partitioned over the ranks (edge_slice): a rank runs the
+    two-view forward + matching of its pairs only, then three all-gathers (indices, valid flags, confidences; slices
+    padded to the largest) give every rank the full result, in edge order, bit-identical to the one-rank call
+    (rows of a batch are computed independently of the batch)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    E = feat_i.shape[0]
+    e0, cnt = edge_slice(E, rank, world)
+    cmax = (E + world - 1) // world
+    dev = feat_i.device
+    HW = None
+    if cnt > 0:
+        sl = slice(e0, e0 + cnt)
+        r = mast3r_match_symmetric(model, feat_i[sl], pos_i[sl], feat_j[sl], pos_j[sl], shape_i[sl], shape_j[sl])
+        HW = r[0].shape[1]
+    hw_t = torch.tensor([HW or 0], device=dev)
+    dist.all_reduce(hw_t, op=dist.ReduceOp.MAX, group=group)     # a rank without pairs learns the pixel count
+    HW = int(hw_t.item())
+    idx = torch.zeros((2, cmax, HW), dtype=torch.long, device=dev)
+    val = torch.zeros((2, cmax, HW), dtype=torch.uint8, device=dev)
+    q = torch.zeros((4, cmax, HW), dtype=torch.float32, device=dev)
+    if cnt > 0:
+        idx[0, :cnt], idx[1, :cnt] = r[0], r[1]
+        val[0, :cnt], val[1, :cnt] = r[2][..., 0].to(torch.uint8), r[3][..., 0].to(torch.uint8)
+        for k in range(4):
+            q[k, :cnt] = r[4 + k][..., 0]
+    out = []
+    for t in (idx, val, q):
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        cols = [parts[p][:, :edge_slice(E, p, world)[1]] for p in range(world)]
+        out.append(torch.cat(cols, dim=1))
+    idx, val, q = out
+    return (idx[0], idx[1], val[0].bool()[..., None], val[1].bool()[..., None], q[0][..., None], q[1][..., None],
+            q[2][..., None], q[3][..., None])
+
+
+def broadcast_keyframe(frame, src=0, group=None):
+    """A keyframe tracked on rank `src` becomes known to the others: encoder tokens + positions (3.1 MB at 512x384),
+    pointmap, confidence and pose - what FactorGraph needs from a keyframe.  In place on every rank."""
+    import torch.distributed as dist
+
+    with torch.inference_mode():     # the tokens were produced under inference mode: in-place writes need it too
+        for t in (frame.feat, frame.pos, frame.X_canon, frame.C, frame.T_WC.data):
+            dist.broadcast(t, src=src, group=group)
 
 
 def edge_slice(E, rank, world):

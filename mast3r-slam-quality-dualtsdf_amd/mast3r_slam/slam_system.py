@@ -84,7 +84,7 @@ class _BackendThread(threading.Thread):
 
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
-                 backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False):
+                 backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0):
         self.model, self.device, self.K = model, torch.device(device), K
         self.keyframes = KeyframeStore() if keyframes is None else keyframes
         self.tracker = FrameTracker(model, self.keyframes, device)
@@ -108,12 +108,19 @@ class SlamSystem:
         assert backend in ("inline", "thread")
         self._lock = threading.RLock()
         self._hand = {"main": None, "backend": None}   # event at the end of each side's last critical section
+        self._commits = []                              # (solve job, event): optimised poses waiting to be written back
         self._worker = _BackendThread(self) if backend == "thread" else None
         self.mode = Mode.INIT
         self.last_T = None
         self.frame_group = max(1, int(frame_group))
         self.enc_stream = torch.cuda.Stream(device=self.device) if self.frame_group > 1 else None
         self._enc_hi = 0
+        # decode_ahead = k > 0: the NEXT group's pair decode is issued on a stream of its own as soon as at most k
+        # already decoded frames are left in front of the current one, so that it runs beside the per-frame matching /
+        # tracking of the current group instead of in front of the next group's first frame (more rows are decoded
+        # in vain when the keyframe changes)
+        self.decode_ahead = max(0, int(decode_ahead)) if self.frame_group > 1 else 0
+        self.dec_stream = torch.cuda.Stream(device=self.device) if self.decode_ahead > 0 else None
         self.stats = dict(frames=0, keyframes=0, group_calls=0, decoded_rows=0, void_rows=0, relocalised=0)
 
     # ------------------------------------------------------------------ frontend (main.py:325-446)
@@ -146,6 +153,7 @@ class SlamSystem:
         """One iteration of the main loop for an already created frame -> dict(mode, new_kf, try_reloc, pose) with
         `pose` = the frame's T_WC data as tracked (before any later backend update of a keyframe copy)."""
         self._wait_encoded(frame)
+        self._wait_decoded(frame)
         if self.last_T is not None:                     # "last camera pose for the frame" (main.py:351-356)
             frame.T_WC = Sim3(self.last_T.data.clone())
         self.stats["frames"] += 1
@@ -154,6 +162,7 @@ class SlamSystem:
         if mode == Mode.RELOC and self._worker is not None:
             self._worker.drain()                        # relocalisation edits the factor graph: the backend must be idle
         with self._critical("main"):
+            self._apply_commits(wait=(mode == Mode.RELOC))
             if mode == Mode.INIT:                       # main.py:359-367
                 X_init, C_init = mu.mast3r_inference_mono(self.model, frame)
                 frame.update_pointmap(X_init, C_init)
@@ -180,9 +189,23 @@ class SlamSystem:
         return dict(mode=mode, new_kf=bool(add_new_kf), try_reloc=bool(try_reloc), pose=frame.T_WC.data.clone())
 
     def drain(self):
-        """Wait until every queued backend task has been issued (backend="thread")."""
+        """Wait until every queued backend task has been issued and its poses are written back (backend="thread")."""
         if self._worker is not None:
             self._worker.drain()
+            with self._critical("main"):
+                self._apply_commits(wait=True)
+
+    def _apply_commits(self, wait=False):
+        """Threaded backend: the global GN runs on copies, outside the hand-over lock; its poses are written into the
+        store HERE, by the tracking side on its own stream, once the solve has finished on the device (the reference's
+        backend process writes them whenever it is done, main.py:145-164 - the frontend never waits for a solve)."""
+        while self._commits:
+            job, ev = self._commits[0]
+            if not wait and not ev.query():
+                return
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self.factor_graph.commit_solve(job)
+            self._commits.pop(0)
 
     def shutdown(self):
         if self._worker is not None:
@@ -222,14 +245,26 @@ class SlamSystem:
         self._worker.q.put((idx, ev))
 
     # ------------------------------------------------------------------ frame groups
-    def _wait_encoded(self, frame):
+    def _wait_encoded(self, frame, stream=None, keep=False):
         ev = getattr(frame, "enc_event", None)
+        if ev is not None:
+            stream = torch.cuda.current_stream(self.device) if stream is None else stream
+            stream.wait_event(ev)
+            frame.feat.record_stream(stream)
+            frame.pos.record_stream(stream)
+            if not keep:
+                frame.enc_event = None
+
+    def _wait_decoded(self, frame):
+        ev = getattr(frame, "dec_event", None)
         if ev is not None:
             main = torch.cuda.current_stream(self.device)
             main.wait_event(ev)
-            frame.feat.record_stream(main)
-            frame.pos.record_stream(main)
-            frame.enc_event = None
+            stash = getattr(frame, "decoded", None)
+            if stash is not None:
+                for t in stash[1]:
+                    t.record_stream(main)
+            frame.dec_event = None
 
     def _look_ahead(self, frames, i, stop=None):
         B, n = self.frame_group, (len(frames) if stop is None else stop)
@@ -247,15 +282,39 @@ class SlamSystem:
         if self.mode != Mode.TRACKING:
             return
         keyframe = self.keyframes.last_keyframe()
-        stash = getattr(frames[i], "decoded", None)
-        if stash is not None and stash[0] == int(keyframe.frame_id):
+        kid = int(keyframe.frame_id)
+
+        def decoded(k):
+            stash = getattr(frames[k], "decoded", None)
+            return stash is not None and stash[0] == kid
+
+        h = i - 1                                        # last frame of the run of frames decoded against this keyframe
+        while h + 1 < n and decoded(h + 1):
+            h += 1
+        if h < i:
+            lo = i                                       # the current frame itself is missing: it has to wait
+        elif self.decode_ahead > 0 and h - i < self.decode_ahead and h + 1 < n:
+            lo = h + 1                                   # few left: the next group, beside this one's tracking
+        else:
             return
-        window = [frames[k] for k in range(i, min(n, i + B))]
+        window = [frames[k] for k in range(lo, min(n, lo + B))]
         for f in window:
-            self._wait_encoded(f)
             if getattr(f, "decoded", None) is not None:  # decoded against a keyframe that has been replaced since
                 self.stats["void_rows"] += 1
-        mu.mast3r_asymmetric_inference_group(self.model, window, keyframe)
+        if self.dec_stream is None:
+            for f in window:
+                self._wait_encoded(f)
+            mu.mast3r_asymmetric_inference_group(self.model, window, keyframe)
+        else:
+            self.dec_stream.wait_stream(main)            # the keyframe (and its features) exist on the tracking stream
+            for f in window:
+                self._wait_encoded(f, self.dec_stream, keep=True)
+            with torch.cuda.stream(self.dec_stream):
+                mu.mast3r_asymmetric_inference_group(self.model, window, keyframe)
+                ev = torch.cuda.Event()
+                ev.record()
+            for f in window:
+                f.dec_event = ev
         self.stats["group_calls"] += 1
         self.stats["decoded_rows"] += len(window)
 
@@ -276,14 +335,35 @@ class SlamSystem:
         frame_idx = [idx] * len(kf_idx)
         if kf_idx:   # symmetric edge inference + matching: reads only the keyframes' (immutable) features
             self.factor_graph.add_factors(kf_idx, frame_idx, config["local_opt"]["min_match_frac"])
-        with self._critical("backend"):
+        kind = "calib" if config["use_calib"] else "rays"
+        if self._worker is None:     # inline: the reference's single_thread order, everything in sequence
             self._solve()
             if self.tsdf_manager is not None:
                 self.tsdf_manager.on_after_backend_solve(self.factor_graph)
-            if self.tsdf_refiner is not None:      # main.py:403-421, after the backend task of the keyframe
-                self.tsdf_refiner.registry.tick()
-                self.tsdf_refiner.maybe_schedule_sliding_window(idx)
-                self.stats["refine_blocks"] = self.stats.get("refine_blocks", 0) + self.tsdf_refiner.process_queue()
+            self._refine(idx)
+            return
+        # threaded: the lock (and with it the tracking stream) is held only while keyframe data is copied out; the
+        # solve and the fusions run on the copies; the poses are written back by the tracking side (_apply_commits)
+        with self._critical("backend"):
+            job = self.factor_graph.prepare_solve(kind)
+            plan = self.tsdf_manager.plan(self.factor_graph) if self.tsdf_manager is not None else None
+        if job is not None:
+            self.factor_graph.run_solve(job)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._commits.append((job, ev))
+        if plan is not None:
+            self.tsdf_manager.execute(plan)
+        if self.tsdf_refiner is not None:
+            torch.cuda.current_stream(self.device).synchronize()   # outside the lock: the refiner reads scalars back
+            with self._critical("backend"):
+                self._refine(idx)
+
+    def _refine(self, idx):
+        if self.tsdf_refiner is not None:      # main.py:403-421, after the backend task of the keyframe
+            self.tsdf_refiner.registry.tick()
+            self.tsdf_refiner.maybe_schedule_sliding_window(idx)
+            self.stats["refine_blocks"] = self.stats.get("refine_blocks", 0) + self.tsdf_refiner.process_queue()
 
     def _solve(self):
         if config["use_calib"]:

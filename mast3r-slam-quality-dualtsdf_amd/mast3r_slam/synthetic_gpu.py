@@ -91,21 +91,37 @@ class RoomRenderer:
         img[:, 0, 0, 0] = (k.to(torch.float64) / TAG_SCALE).float()
         return img
 
+    def _hash01(self, ki, kj, salt, channels=1):
+        """Deterministic pseudo-random field in [0,1) per (pair, pixel, channel): the stand-in's noise must not depend on
+        the order or the batching of the calls (the sharded backend decodes an edge on whichever rank owns it)."""
+        B = ki.shape[0]
+        pix = torch.arange(self.h * self.w, device=self.device, dtype=torch.float64)
+        ch = torch.arange(channels, device=self.device, dtype=torch.float64)
+        x = (pix[None, :, None] * 0.618033988749895 + ch[None, None, :] * 0.754877666246693
+             + (ki.double() * 12.9898 + kj.double() * 78.233 + salt * 37.719)[:, None, None])
+        v = torch.sin(x * 12.9898) * 43758.5453
+        return (v - torch.floor(v)).reshape(B, self.h * self.w, channels)
+
     def pair(self, ki, kj, noise=0.002, generator=None):
         """Two-view geometry in MASt3R's output convention for view i (path index ki) and view j, both (B,):
-        res1 = view i in frame i, res2 = view j expressed in frame i (synthetic.make_pair)."""
+        res1 = view i in frame i, res2 = view j expressed in frame i (synthetic.make_pair).  Point noise (Gaussian,
+        `noise` metres) and the confidence maps are deterministic functions of (ki, kj, pixel); `generator` is unused
+        and kept for the signature."""
         B, h, w = ki.shape[0], self.h, self.w
         Ti, Tj = camera_pose_t(ki, self.n_frames), camera_pose_t(kj, self.n_frames)
         Xi_i, Xj_j = self.pointmap(Ti), self.pointmap(Tj)
         Pw_i, Pw_j = sim3_act_t(Ti, Xi_i), sim3_act_t(Tj, Xj_j)
         Xj_i = sim3_act_t(sim3_inv_t(Ti), Pw_j)
-        rnd = lambda *s: torch.randn(*s, device=self.device, generator=generator)
-        uni = lambda lo, hi: torch.rand(B, h, w, device=self.device, generator=generator) * (hi - lo) + lo
         out = []
-        for X, Pw in ((Xi_i, Pw_i), (Xj_i, Pw_j)):
-            out.append(dict(pts3d=(X.float() + noise * rnd(B, h * w, 3)).reshape(B, h, w, 3),
-                            conf=uni(1.0, 3.0), desc=self.descriptors(Pw).float().reshape(B, h, w, -1),
-                            desc_conf=uni(1.5, 4.0)))
+        for side, (X, Pw) in enumerate(((Xi_i, Pw_i), (Xj_i, Pw_j))):
+            u1 = self._hash01(ki, kj, 4 * side + 0, 3).clamp_min(1e-12)
+            u2 = self._hash01(ki, kj, 4 * side + 1, 3)
+            gauss = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2 * math.pi * u2)          # Box-Muller
+            conf = 1.0 + 2.0 * self._hash01(ki, kj, 4 * side + 2)[..., 0]
+            dconf = 1.5 + 2.5 * self._hash01(ki, kj, 4 * side + 3)[..., 0]
+            out.append(dict(pts3d=(X + noise * gauss).float().reshape(B, h, w, 3), conf=conf.float().reshape(B, h, w),
+                            desc=self.descriptors(Pw).float().reshape(B, h, w, -1),
+                            desc_conf=dconf.float().reshape(B, h, w)))
         return out[0], out[1]
 
 

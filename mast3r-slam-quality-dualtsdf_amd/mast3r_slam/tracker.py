@@ -50,16 +50,23 @@ class FrameTracker:
         valid_opt = valid_match_k & valid_Cf & valid_Ck & valid_Q
         valid_kf = valid_match_k & valid_Q
 
-        match_frac = valid_opt.sum() / valid_opt.numel()
-        if match_frac < self.cfg["min_match_frac"]:
-            return False, [], True
-
+        # ONE host read per tracked frame: the reference branches on the host four times (match fraction :72-75, solver
+        # failure :91-93, the two fractions of the keyframe decision :170-177).  Here the solver is enqueued
+        # unconditionally (its result is dropped when the match-fraction gate fails) and the five scalars come back in
+        # one small copy; the unique count is a scatter instead of torch.unique (no second synchronisation).
+        match_frac = valid_opt.float().mean()
         if not use_calib:
-            T_WCf, T_CkCf, ok = self.opt_pose_ray_dist_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid_opt)
+            T_WCf, T_CkCf, status = self._run_async(False, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, None, None)
         else:
-            T_WCf, T_CkCf, ok = self.opt_pose_calib_sim3(Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, meas_k,
-                                                         valid_meas_k, K, img_size)
-        if not ok:  # "Cholesky failed" (tracker.py:91-93)
+            T_WCf, T_CkCf, status = self._run_async(True, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, K, img_size)
+        hits = torch.zeros(valid_kf.numel(), dtype=torch.int32, device=idx_f2k.device)
+        hits.index_add_(0, idx_f2k, valid_match_k[:, 0].to(torch.int32))
+        verdict = torch.stack((match_frac, status[1].float(), status[2].float(), valid_kf.float().mean(),
+                               (hits > 0).float().mean())).cpu()
+        self.last_iters = int(verdict[1])
+        if float(verdict[0]) < self.cfg["min_match_frac"]:
+            return False, [], True
+        if int(verdict[2]) != 0:  # "Cholesky failed" (tracker.py:91-93)
             return False, [], True
 
         if self.quality_service is not None and not use_calib:   # tracker.py:94-145 (ray-distance residual form)
@@ -79,9 +86,7 @@ class FrameTracker:
         keyframe.update_pointmap(Xkk, Ckf)
         self.keyframes[len(self.keyframes) - 1] = keyframe
 
-        n_valid = valid_kf.sum()
-        match_frac_k = n_valid / valid_kf.numel()
-        unique_frac_f = torch.unique(idx_f2k[valid_match_k[:, 0]]).shape[0] / valid_kf.numel()
+        match_frac_k, unique_frac_f = float(verdict[3]), float(verdict[4])
         new_kf = min(match_frac_k, unique_frac_f) < self.cfg["match_frac_thresh"]
         if new_kf:
             self.reset_idx_f2k()
@@ -102,6 +107,14 @@ class FrameTracker:
 
     # ------------------------------------------------------------------
     def _run(self, use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None):
+        T_WCf_new, T_CkCf, status = self._run_async(use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx)
+        st = status.cpu()   # synchronous form (opt_pose_* keep the reference's (T_WCf, T_CkCf, ok) return)
+        self.last_iters = int(st[1])
+        return T_WCf_new, T_CkCf, int(st[2]) == 0
+
+    def _run_async(self, use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None):
+        """Enqueues the whole GN loop; returns (T_WCf, T_CkCf, status) with `status` a device i32[8]
+        ([done, iterations, failed, ...]) that the caller reads when it needs the verdict."""
         cfg = self.cfg
         dev = Xf.device
         idx = self._idx if idx is None else idx
@@ -123,9 +136,7 @@ class FrameTracker:
         _m.check(rc, "track_pose")
         T_CkCf = Sim3(T_rel.reshape(1, 8))
         T_WCf_new = T_WCk * T_CkCf
-        st = self._status.cpu()   # the one host sync of the tracking step (the caller needs the verdict)
-        self.last_iters = int(st[1])
-        return T_WCf_new, T_CkCf, int(st[2]) == 0
+        return T_WCf_new, T_CkCf, self._status
 
     def opt_pose_ray_dist_sim3(self, Xf, Xk, T_WCf, T_WCk, Qk, valid, idx=None):
         """tracker.py:225-266 -> (T_WCf, T_CkCf, ok)."""

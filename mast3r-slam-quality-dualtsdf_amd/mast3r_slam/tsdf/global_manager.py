@@ -55,13 +55,26 @@ class TSDFGlobalIntegrator:
         self._integrate_new_keyframes()
         self._process_dirty_queue()
 
+    def snapshot(self, idx):
+        """The copies _integrate_single takes under the keyframes lock (global_manager.py:82-88): X, C, T_WC."""
+        if idx >= len(self.keyframes):
+            return None
+        frame = self.keyframes[idx]
+        return (frame.X_canon.detach().clone(), frame.C.detach().clone(), frame.T_WC.data.clone())
+
     def _integrate_single(self, idx):
         """global_manager.py:81-106: random subset (<= max_points_per_kf) of the points with C > min_confidence,
         moved to the world frame with T_WC, fused with the camera centre as ray origin.  Everything stays on
         the device (the reference round-trips through numpy because its volume is a python dict)."""
-        if idx >= len(self.keyframes):
+        self._integrate_snapshot(self.snapshot(idx))
+
+    def _integrate_snapshot(self, snap):
+        if snap is None:
             return
-        frame = self.keyframes[idx]
+
+        class frame:   # the three tensors of the snapshot under the names used below
+            X_canon, C, T_WC = snap[0], snap[1], Sim3(snap[2])
+
         points = frame.X_canon.detach().reshape(-1, 3)
         conf = frame.C.detach().reshape(-1)
         valid_idx = torch.nonzero(conf > self.min_conf).view(-1)
@@ -107,15 +120,13 @@ class TSDFGlobalManager:
     def start(self):
         pass
 
-    def _maintain(self):
+    def _maintain(self, n_fusions):
         """One small D2H read per solve, BEFORE its work: samples dropped by the previous solve raise; the table grows so
-        that everything this solve may insert (the not yet fused keyframes + the re-fusion budget, every in-band sample
-        a new voxel) still leaves it half empty - the table cannot grow in the middle of an integrate."""
+        that everything this solve may insert (`n_fusions` keyframes, every in-band sample a new voxel) still leaves
+        it half empty - the table cannot grow in the middle of an integrate."""
         v = self.volume
         band = int(2.0 * v.truncation / (0.5 * v.voxel_size)) + 4
-        n_new = max(0, len(self.keyframes) - self.integrator.next_idx)
-        n_re = self.reintegrate_budget if self.reintegrate_budget > 0 else self.integrator.max_pending
-        self.volume.maintain(reserve=(n_new + n_re) * self.integrator.max_points * band)
+        self.volume.maintain(reserve=n_fusions * self.integrator.max_points * band)
 
     def shutdown(self):
         if self.enabled:
@@ -123,22 +134,45 @@ class TSDFGlobalManager:
 
     def on_after_backend_solve(self, factor_graph):
         """global_manager.py:213-226, followed by the pass the reference's two threads would make."""
+        self.execute(self.plan(factor_graph))
+
+    # The hook in two halves for a threaded owner: plan() does the queue bookkeeping and takes the copies of the keyframe
+    # tensors the fusions need (what the reference does under keyframes.lock) - no host synchronisation; execute() does
+    # the device work on those copies.  The pose optimiser still reads and writes the store directly, so a threaded
+    # owner must run execute() where that is safe whenever `sync_optimize_per_solve` leaves it work (max_iterations > 0).
+    def plan(self, factor_graph):
         if not self.enabled:
-            return
-        self._maintain()
-        self.integrator._integrate_new_keyframes()
+            return None
+        integ = self.integrator
+        new = list(range(integ.next_idx, len(self.keyframes)))
+        todo = [("new", i, integ.snapshot(i)) for i in new]
+        integ.next_idx = len(self.keyframes)
+        batch = []
         idx_tensor = getattr(factor_graph, "last_unique_kf_idx", None)
-        if idx_tensor is None:
+        if idx_tensor is not None:
+            pin = int(config.get("local_opt", {}).get("pin", 1))
+            indices = [int(i) for i in idx_tensor.tolist() if int(i) >= pin]
+            if indices:
+                integ.mark_pose_update(indices)
+                done = 0
+                while integ.pending and (self.reintegrate_budget <= 0 or done < self.reintegrate_budget):
+                    i = integ.pending.pop(0)
+                    if i < len(self.keyframes):
+                        todo.append(("dirty", i, integ.snapshot(i)))
+                        done += 1
+                for i in indices:      # TSDFGlobalOptThread.enqueue
+                    if i not in self.opt_pending and len(self.opt_pending) < self.max_opt_pending:
+                        self.opt_pending.append(i)
+                n = len(self.opt_pending) if self.optimize_budget <= 0 else min(self.optimize_budget, len(self.opt_pending))
+                batch, self.opt_pending = self.opt_pending[:n], self.opt_pending[n:]
+        return dict(todo=todo, optimize=batch)
+
+    def execute(self, plan):
+        if plan is None:
             return
-        pin = int(config.get("local_opt", {}).get("pin", 1))
-        indices = [int(i) for i in idx_tensor.cpu().tolist() if int(i) >= pin]
-        if not indices:
-            return
-        self.integrator.mark_pose_update(indices)
-        self.integrator._process_dirty_queue(self.reintegrate_budget)
-        for i in indices:      # TSDFGlobalOptThread.enqueue
-            if i not in self.opt_pending and len(self.opt_pending) < self.max_opt_pending:
-                self.opt_pending.append(i)
-        n = len(self.opt_pending) if self.optimize_budget <= 0 else min(self.optimize_budget, len(self.opt_pending))
-        batch, self.opt_pending = self.opt_pending[:n], self.opt_pending[n:]
-        self.optimizer.optimize_keyframes(batch, context="factor")
+        self._maintain(len(plan["todo"]))
+        for kind, i, snap in plan["todo"]:
+            self.integrator._integrate_snapshot(snap)
+            if kind == "new":
+                self.optimizer.pre_refine(i)
+        self.optimizer.optimize_keyframes(plan["optimize"], context="factor")

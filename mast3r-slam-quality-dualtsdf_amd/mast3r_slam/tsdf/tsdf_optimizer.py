@@ -37,7 +37,7 @@ class TSDFPoseOptimizer:
     def _optimize_single(self, idx, iterations, sample_override=0, log_prefix="[TSDF]"):
         """tsdf_optimizer.py:46-92: sample <= samples_per_kf points with C > min_confidence (torch.randperm,
         as the reference), iterate pose <- exp(delta) * pose against the volume, write T_WC back."""
-        if idx >= len(self.keyframes):
+        if idx >= len(self.keyframes) or iterations <= 0:
             return
         frame = self.keyframes[idx]
         points = frame.X_canon.detach().reshape(-1, 3)

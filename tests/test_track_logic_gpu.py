@@ -36,11 +36,14 @@ def test_track_gates_and_fusion(device, golden_dir, monkeypatch, name):
     seen = {}
     pose = lambda k: Sim3(torch.from_numpy(fx[k].astype(np.float32)).reshape(1, 8).to(device))
 
-    def solver(Xf, Xk, T_WCf, T_WCk, Qk, valid, idx=None):
+    def solver(use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None):
+        # the enqueue-only form track() uses: (T_WCf, T_CkCf, device status [done, iterations, failed, ...]); track()
+        # reaches it even when the match-fraction gate fails (the verdict is read once, after the solve is enqueued)
         seen["Qk"], seen["valid"] = Qk.cpu().numpy(), valid.cpu().numpy()
-        return pose("T_new"), pose("T_rel"), name != "solver_fails"
+        status = torch.tensor([1, 3, int(name == "solver_fails"), 0, 0, 0, 0, 0], dtype=torch.int32, device=device)
+        return pose("T_new"), pose("T_rel"), status
 
-    monkeypatch.setattr(tr, "opt_pose_ray_dist_sim3", solver)
+    monkeypatch.setattr(tr, "_run_async", solver)
     new_kf, info, skipped = tr.track(fr)
     want = fx[f"{name}_ret"]
     assert [bool(new_kf), bool(skipped), tr.idx_f2k is None] == want.tolist()
