@@ -245,12 +245,14 @@ int mslam_mast3r_decode(void* handle, const float* feat1, const float* feat2, in
  * (rel. cost decrease < rel_error or |tau| < delta_norm) is a device flag.  status_out (device,
  * 32 bytes, may be NULL) <- {i32 done, i32 iters, i32 chol_fail, f32 old_cost, f32 last_cost,
  * f32 last_delta_norm, -, -}; chol_fail mirrors the exception path of tracker.py:72-93.
+ * The loop state lives in `workspace`: iterations [first_iter, max_iters) are enqueued, first_iter == 0 resets the
+ * state, so a caller may enqueue a first chunk, read the status and continue only when `done` is still 0.
  * ------------------------------------------------------------------------------------------ */
 size_t mslam_track_workspace_bytes(int n_points);
 int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, const float* Xk, const int64_t* idx_f2k,
                      const float* Qk, const uint8_t* valid, int n_points, const float* K, int width,
                      int height, float sigma_a, float sigma_b, float huber, int pixel_border, float z_eps,
-                     int max_iters, float rel_error, float delta_norm, void* status_out, void* workspace,
+                     int first_iter, int max_iters, float rel_error, float delta_norm, void* status_out, void* workspace,
                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -316,6 +318,17 @@ int mslam_quality_reduce_grid(const float* x, const float* y, const uint8_t* val
                               double c_thr, double q_thr, float* out, void* stream);
 int mslam_quality_classify(const float* delta_cov, const float* r, const float* u, int n, float thr_zr, float thr_zu,
                            float thr_dc, int64_t* cls, float* pri, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic-data source (NOT a reference interface): the procedural box room of mast3r_slam/synthetic.py rendered
+ * for `batch` view pairs in one kernel, in the layout of the MASt3R heads' outputs (X f32[b,h,w,3], C f32[b,h,w],
+ * D f32[b,h,w,24], Q f32[b,h,w]; side 1 = view i in frame i, side 2 = view j in frame i).  ki / kj: device f32[batch]
+ * camera-path indices; Wm (3x24) and phase (24): HOST doubles of the descriptor field.  Stands in for a trained
+ * network's output in runs without a checkpoint (mast3r_slam/synthetic_gpu.py, bench.py).
+ * ------------------------------------------------------------------------------------------ */
+int mslam_room_pair(const float* ki, const float* kj, int batch, int h, int w, int n_frames, double fx, double fy,
+                    double cx, double cy, double noise, const double* Wm_3x24, const double* phase_24, float* X1,
+                    float* C1, float* D1, float* Q1, float* X2, float* C2, float* D2, float* Q2, void* stream);
 
 #ifdef __cplusplus
 }

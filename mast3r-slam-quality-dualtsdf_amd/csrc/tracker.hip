@@ -209,9 +209,9 @@ extern "C" size_t mslam_track_workspace_bytes(int n_points) {
 extern "C" int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, const float* Xk, const int64_t* idx_f2k,
                                 const float* Qk, const uint8_t* valid, int n_points, const float* K, int width,
                                 int height, float sigma_a, float sigma_b, float huber, int pixel_border, float z_eps,
-                                int max_iters, float rel_error, float delta_norm, void* status_out, void* workspace,
-                                size_t workspace_bytes, void* stream) {
-  MSLAM_REQUIRE(n_points > 0 && max_iters >= 0, "track_pose: bad sizes");
+                                int first_iter, int max_iters, float rel_error, float delta_norm, void* status_out,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  MSLAM_REQUIRE(n_points > 0 && max_iters >= 0 && first_iter >= 0, "track_pose: bad sizes");
   MSLAM_REQUIRE(T_rel && Xf && Xk && idx_f2k && Qk && valid && workspace, "track_pose: null pointer");
   MSLAM_REQUIRE(!use_calib || (K && width > 0 && height > 0), "track_pose: calib needs K, width, height");
   MSLAM_REQUIRE(workspace_bytes >= mslam_track_workspace_bytes(n_points), "track_pose: workspace too small");
@@ -229,8 +229,8 @@ extern "C" int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, co
     P.border_lo = (float)pixel_border; P.border_hi_u = (float)(width - 1 - pixel_border);
     P.border_hi_v = (float)(height - 1 - pixel_border); P.z_eps = z_eps;
   }
-  hipLaunchKernelGGL(track_init_kernel, dim3(1), dim3(1), 0, s, st);
-  for (int it = 0; it < max_iters; it++) {
+  if (first_iter == 0) hipLaunchKernelGGL(track_init_kernel, dim3(1), dim3(1), 0, s, st);
+  for (int it = first_iter; it < max_iters; it++) {
     if (use_calib)
       hipLaunchKernelGGL(track_accum_kernel<1>, dim3(nblk), dim3(256), 0, s, st, T_rel, Xf, Xk, idx_f2k, Qk, valid,
                          n_points, P, partial);

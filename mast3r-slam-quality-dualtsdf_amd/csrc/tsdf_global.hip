@@ -274,8 +274,12 @@ __global__ __launch_bounds__(256) void tsdf_scatter_kernel(void* base, uint64_t 
 }
 
 // one thread per touched voxel: apply its samples in the reference's order (global_volume.py:74-88)
+constexpr uint32_t kSortMax = 48;
+
 __global__ __launch_bounds__(256) void tsdf_replay_kernel(void* base, uint64_t cap, IntegrateScratch S,
                                                           double max_weight) {
+  __shared__ uint32_t s_seq[256][kSortMax + 1];   // odd row stride: the rows of a wave fall on different banks
+  __shared__ uint8_t s_pos[256][kSortMax + 4];
   TsdfTable t = table_carve(base, cap);
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= t.hdr->n_touched) return;
@@ -283,17 +287,9 @@ __global__ __launch_bounds__(256) void tsdf_replay_kernel(void* base, uint64_t c
   const uint32_t L = t.cnt[slot], o = t.off[slot];
   double tsdf = t.tsdf[slot], weight = t.weight[slot];
   uint8_t state = t.state[slot];
-  long long last = -1;
-  for (uint32_t r = 0; r < L; r++) {
-    // selection: smallest sequence number greater than the last one applied
-    uint32_t best = 0xFFFFFFFFu, bj = 0;
-    for (uint32_t j = 0; j < L; j++) {
-      const uint32_t s = S.seg_seq[o + j];
-      if ((long long)s > last && s < best) { best = s; bj = j; }
-    }
-    last = best;
-    const double tv = (double)S.seg_tsdf[o + bj];
-    const double w = S.seg_w[o + bj];
+  auto apply = [&](uint32_t j) {
+    const double tv = (double)S.seg_tsdf[o + j];
+    const double w = S.seg_w[o + j];
     if (state == 0) {  // first touch: stored as given, not averaged, not clamped
       tsdf = tv; weight = w; state = 1;
     } else {
@@ -302,6 +298,31 @@ __global__ __launch_bounds__(256) void tsdf_replay_kernel(void* base, uint64_t c
       tsdf = (tsdf * weight + tv * w) / (total > 1.0e-9 ? total : 1.0e-9);
       weight = total;
       state = 2;
+    }
+  };
+  if (L <= kSortMax) {
+    // the usual case (a voxel sees ~10 samples of a keyframe): sequence numbers are read ONCE, insertion-sorted in
+    // this thread's LDS row, then the records are applied in that order
+    uint32_t* sq = &s_seq[threadIdx.x][0];
+    uint8_t* sp = &s_pos[threadIdx.x][0];
+    for (uint32_t r = 0; r < L; r++) {
+      const uint32_t v = S.seg_seq[o + r];
+      uint32_t k = r;
+      while (k > 0 && sq[k - 1] > v) { sq[k] = sq[k - 1]; sp[k] = sp[k - 1]; k--; }
+      sq[k] = v; sp[k] = (uint8_t)r;
+    }
+    for (uint32_t r = 0; r < L; r++) apply(sp[r]);
+  } else {
+    long long last = -1;
+    for (uint32_t r = 0; r < L; r++) {
+      // selection: smallest sequence number greater than the last one applied
+      uint32_t best = 0xFFFFFFFFu, bj = 0;
+      for (uint32_t j = 0; j < L; j++) {
+        const uint32_t sv = S.seg_seq[o + j];
+        if ((long long)sv > last && sv < best) { best = sv; bj = j; }
+      }
+      last = best;
+      apply(bj);
     }
   }
   t.tsdf[slot] = tsdf; t.weight[slot] = weight; t.state[slot] = state;

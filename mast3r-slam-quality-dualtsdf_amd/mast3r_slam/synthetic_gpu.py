@@ -64,6 +64,9 @@ class RoomRenderer:
         self.Wm = torch.from_numpy(rng.normal(0, 6.0, (3, fdim))).to(device)
         self.ph = torch.from_numpy(rng.uniform(0, 2 * np.pi, fdim)).to(device)
         self.half = torch.from_numpy(synthetic.ROOM_HALF).to(device)
+        self.K = K
+        self._Wm_host = np.ascontiguousarray(self.Wm.cpu().numpy(), np.float64)
+        self._ph_host = np.ascontiguousarray(self.ph.cpu().numpy(), np.float64)
 
     def pointmap(self, T):
         """(B,8) f64 -> camera-frame points (B,HW,3) f64 (synthetic.render_pointmap)."""
@@ -101,6 +104,23 @@ class RoomRenderer:
              + (ki.double() * 12.9898 + kj.double() * 78.233 + salt * 37.719)[:, None, None])
         v = torch.sin(x * 12.9898) * 43758.5453
         return (v - torch.floor(v)).reshape(B, self.h * self.w, channels)
+
+    def pair_fused(self, ki, kj, noise=0.002):
+        """pair() as ONE kernel (csrc/room.hip): same formulas, fused; device tensors only."""
+        import mslam_hip as _m
+
+        B, h, w = ki.shape[0], self.h, self.w
+        f32 = dict(dtype=torch.float32, device=self.device)
+        out = [dict(pts3d=torch.empty((B, h, w, 3), **f32), conf=torch.empty((B, h, w), **f32),
+                    desc=torch.empty((B, h, w, 24), **f32), desc_conf=torch.empty((B, h, w), **f32)) for _ in range(2)]
+        kif, kjf = ki.float().contiguous(), kj.float().contiguous()
+        K = self.K
+        rc = _m.lib().mslam_room_pair(
+            _m.ptr(kif), _m.ptr(kjf), B, h, w, self.n_frames, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]),
+            float(K[1, 2]), float(noise), self._Wm_host.ctypes.data, self._ph_host.ctypes.data,
+            *[_m.ptr(out[s_][k]) for s_ in range(2) for k in ("pts3d", "conf", "desc", "desc_conf")], _m.stream_ptr())
+        _m.check(rc, "room_pair")
+        return out[0], out[1]
 
     def pair(self, ki, kj, noise=0.002, generator=None):
         """Two-view geometry in MASt3R's output convention for view i (path index ki) and view j, both (B,):
@@ -155,6 +175,8 @@ class RoomGeometryModel:
         self.dec_rows += feat1.shape[0]
         if self.net is not None:
             self.net.decode_pair(feat1, feat2, h, w)     # the real two-view forward; its outputs are dropped
+        if feat1.is_cuda:
+            return self.room.pair_fused(feat1[:, 0, 0], feat2[:, 0, 0], self.noise)
         return self.room.pair(feat1[:, 0, 0], feat2[:, 0, 0], self.noise, self.gen)
 
 

@@ -56,13 +56,18 @@ class FrameTracker:
         # one small copy; the unique count is a scatter instead of torch.unique (no second synchronisation).
         match_frac = valid_opt.float().mean()
         if not use_calib:
-            T_WCf, T_CkCf, status = self._run_async(False, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, None, None)
+            T_WCf, T_CkCf, status = self._run_async(False, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, None, None, chunked=True)
         else:
-            T_WCf, T_CkCf, status = self._run_async(True, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, K, img_size)
+            T_WCf, T_CkCf, status = self._run_async(True, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, K, img_size, chunked=True)
         hits = torch.zeros(valid_kf.numel(), dtype=torch.int32, device=idx_f2k.device)
         hits.index_add_(0, idx_f2k, valid_match_k[:, 0].to(torch.int32))
-        verdict = torch.stack((match_frac, status[1].float(), status[2].float(), valid_kf.float().mean(),
-                               (hits > 0).float().mean())).cpu()
+        pack = lambda st: torch.stack((match_frac, st[1].float(), st[2].float(), valid_kf.float().mean(),
+                                       (hits > 0).float().mean(), st[0].float())).cpu()
+        verdict = pack(status)
+        if float(verdict[0]) >= self.cfg["min_match_frac"] and int(verdict[5]) == 0 and int(verdict[2]) == 0 \
+                and int(verdict[1]) < int(self.cfg["max_iters"]):
+            T_WCf, T_CkCf, status = self._run_rest()     # rare: the loop needs more than the first chunk
+            verdict = pack(status)
         self.last_iters = int(verdict[1])
         if float(verdict[0]) < self.cfg["min_match_frac"]:
             return False, [], True
@@ -112,9 +117,13 @@ class FrameTracker:
         self.last_iters = int(st[1])
         return T_WCf_new, T_CkCf, int(st[2]) == 0
 
-    def _run_async(self, use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None):
-        """Enqueues the whole GN loop; returns (T_WCf, T_CkCf, status) with `status` a device i32[8]
-        ([done, iterations, failed, ...]) that the caller reads when it needs the verdict."""
+    FIRST_CHUNK = 8   # iterations enqueued before the verdict is read; the rest only if the loop has not finished
+
+    def _run_async(self, use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None, chunked=False):
+        """Enqueues the GN loop; returns (T_WCf, T_CkCf, status) with `status` a device i32[8]
+        ([done, iterations, failed, ...]) that the caller reads when it needs the verdict.  chunked=True enqueues only
+        the first FIRST_CHUNK iterations (a tracked frame needs ~5; 50 launch pairs that exit at once would cost more
+        host time than the solve): the caller checks `done` and calls _run_rest when the loop is still running."""
         cfg = self.cfg
         dev = Xf.device
         idx = self._idx if idx is None else idx
@@ -127,16 +136,27 @@ class FrameTracker:
             self._status = torch.zeros(8, dtype=torch.int32, device=dev)
         h, w = (int(img_size[0]), int(img_size[1])) if img_size is not None else (0, 0)
         sa, sb = (cfg["sigma_pixel"], cfg["sigma_depth"]) if use_calib else (cfg["sigma_ray"], cfg["sigma_dist"])
-        rc = L.mslam_track_pose(
-            int(use_calib), _m.ptr(T_rel), _m.ptr(Xf.contiguous()), _m.ptr(Xk.contiguous()), _m.ptr(idx.contiguous()),
-            _m.ptr(Qk.reshape(-1).contiguous()), _m.ptr(valid.reshape(-1).contiguous()), n,
-            _m.ptr(K.contiguous()) if use_calib else 0, w, h, float(sa), float(sb), float(cfg["huber"]),
-            int(cfg["pixel_border"]), float(cfg["depth_eps"]), int(cfg["max_iters"]), float(cfg["rel_error"]),
-            float(cfg["delta_norm"]), _m.ptr(self._status), _m.ptr(self._ws), self._ws.numel(), _m.stream_ptr())
+        self._job = dict(args=(int(use_calib), _m.ptr(T_rel), _m.ptr(Xf.contiguous()), _m.ptr(Xk.contiguous()),
+                               _m.ptr(idx.contiguous()), _m.ptr(Qk.reshape(-1).contiguous()),
+                               _m.ptr(valid.reshape(-1).contiguous()), n, _m.ptr(K.contiguous()) if use_calib else 0,
+                               w, h, float(sa), float(sb), float(cfg["huber"]), int(cfg["pixel_border"]),
+                               float(cfg["depth_eps"])),
+                         keep=(T_rel, Xf, Xk, idx, Qk, valid, K), T_rel=T_rel, T_WCk=T_WCk)
+        last = min(self.FIRST_CHUNK, int(cfg["max_iters"])) if chunked else int(cfg["max_iters"])
+        return self._enqueue(0, last)
+
+    def _enqueue(self, first, last):
+        cfg, job = self.cfg, self._job
+        rc = _m.lib().mslam_track_pose(*job["args"], int(first), int(last), float(cfg["rel_error"]),
+                                       float(cfg["delta_norm"]), _m.ptr(self._status), _m.ptr(self._ws),
+                                       self._ws.numel(), _m.stream_ptr())
         _m.check(rc, "track_pose")
-        T_CkCf = Sim3(T_rel.reshape(1, 8))
-        T_WCf_new = T_WCk * T_CkCf
-        return T_WCf_new, T_CkCf, self._status
+        T_CkCf = Sim3(job["T_rel"].reshape(1, 8))
+        return job["T_WCk"] * T_CkCf, T_CkCf, self._status
+
+    def _run_rest(self):
+        """The iterations behind the first chunk (same loop state, same results as one uninterrupted loop)."""
+        return self._enqueue(min(self.FIRST_CHUNK, int(self.cfg["max_iters"])), int(self.cfg["max_iters"]))
 
     def opt_pose_ray_dist_sim3(self, Xf, Xk, T_WCf, T_WCk, Qk, valid, idx=None):
         """tracker.py:225-266 -> (T_WCf, T_CkCf, ok)."""

@@ -48,13 +48,14 @@ _SIGNATURES = {
     "mslam_conv2d_nhwc_bf16": [_c_vp] * 5 + [_c_int] * 9 + [_c_vp],
     "mslam_attention_bf16": [_c_vp] * 4 + [_c_int] * 4 + [_c_vp],
     "mslam_layernorm_f32": [_c_vp] * 5 + [_c_int, _c_int, _c_float, _c_vp],
-    "mslam_track_pose": [_c_int] + [_c_vp] * 6 + [_c_int, _c_vp, _c_int, _c_int] + [_c_float] * 3 + [_c_int, _c_float, _c_int, _c_float, _c_float, _c_vp, _c_vp, _c_size, _c_vp],
+    "mslam_track_pose": [_c_int] + [_c_vp] * 6 + [_c_int, _c_vp, _c_int, _c_int] + [_c_float] * 3 + [_c_int, _c_float, _c_int, _c_int, _c_float, _c_float, _c_vp, _c_vp, _c_size, _c_vp],
     "mslam_tsdf_local_build": [_c_vp] * 5 + [_c_int] * 4 + [_c_double, _c_double, _c_float, _c_vp, _c_vp, _c_vp, _c_size, _c_vp],
     "mslam_tsdf_local_raycast": [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_float, _c_vp, _c_vp, _c_vp],
     "mslam_quality_reduce_grid": [_c_vp] * 3 + [_c_int] * 4 + [_c_double, _c_double, _c_vp, _c_vp],
     "mslam_quality_classify": [_c_vp] * 3 + [_c_int] + [_c_float] * 3 + [_c_vp] * 3,
     "mslam_tsdf_table_init": [_c_vp, _c_size, ctypes.c_uint64, _c_vp],
     "mslam_tsdf_integrate": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp, _c_vp, _c_int] + [_c_double] * 4 + [_c_int, _c_int, _c_vp, _c_size, _c_vp],
+    "mslam_room_pair": [_c_vp, _c_vp] + [_c_int] * 4 + [_c_double] * 5 + [_c_vp] * 10 + [_c_vp],
     "mslam_tsdf_rehash": [_c_vp, ctypes.c_uint64, _c_vp, ctypes.c_uint64, _c_vp],
     "mslam_tsdf_header": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp],
     "mslam_tsdf_dump": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp, _c_vp, ctypes.c_uint32, _c_vp],
