@@ -179,6 +179,26 @@ def dominant_shape(B):
     return 768 * B, 4096, 1024
 
 
+def isolated_dominant_us(L, m, M, N, K, dev, iters=50):
+    """The dominant kernel alone on the GPU (nothing else running), event-timed: what the live figure would be without
+    the other streams' kernels sharing the chip (the profiles under profiles/ are taken this way)."""
+    A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    Wt = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    call = lambda: L.mslam_gemm_bf16(m.ptr(A), m.ptr(Wt), m.ptr(bias), 0, m.ptr(out), M, N, K, 1, 1, m.stream_ptr())
+    for _ in range(5):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / iters
+
+
 def cpu_baseline(args, graph_kfs, graph_edges, edges_per_kf, kf_every):
     """The oracle (kind = "port") timed on the host cores for a BOUNDED sample of the same workload:
     one tracked frame (torch-CPU fp32 network restatement + C matching + numpy tracking GN) plus one
@@ -333,6 +353,7 @@ def main():
                     "gemm_profile_end")
     kf1, e1 = ses.graph()
     st1 = dict(ses.system.stats)
+    iso_us = isolated_dominant_us(L, mslam_hip, M, N, K, dev) if not args.no_network else 0.0
     enc_rows, dec_rows = ses.model.enc_rows - rows0[0], ses.model.dec_rows - rows0[1]
     if world > 1:
         import torch.distributed as dist
@@ -387,6 +408,8 @@ def main():
                          "kernel": f"gemm_bf16_kernel, encoder fc1 {M}x{N}x{K} + GELU (largest share of the step)",
                          "gflop_per_launch": dom_gflop, "us_per_launch_avg": avg_us.value, "us_per_launch_min": min_us.value,
                          "launches_timed": nsamp.value,
+                         "us_per_launch_isolated": iso_us,
+                         "tflops_isolated": dom_gflop * 1e3 / iso_us if iso_us else 0.0,
                          "method": "HIP events around every launch of this shape inside the timed region, on its launch stream "
                                    "(mslam_gemm_profile_begin/end)",
                          "network_tflops_over_timed_region": gflop / (1e3 * elapsed) if elapsed > 0 else 0.0,
