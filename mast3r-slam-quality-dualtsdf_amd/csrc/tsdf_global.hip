@@ -37,7 +37,7 @@ struct TsdfHeader {
   uint32_t seg_cursor;   // scratch
   uint32_t fused;        // points fused by the last integrate (return value of the reference)
   uint32_t dump_cursor;
-  uint32_t pad;
+  uint32_t n_big;        // scratch: voxels with more samples than a thread sorts itself (replayed by a wave each)
 };
 
 struct TsdfTable {
@@ -135,7 +135,7 @@ __global__ void tsdf_init_kernel(void* base, uint64_t cap) {
   if (i == 0) {
     TsdfHeader h;
     h.capacity = cap; h.count = 0; h.overflow = 0; h.n_records = 0; h.n_touched = 0; h.seg_cursor = 0;
-    h.fused = 0; h.dump_cursor = 0; h.pad = 0;
+    h.fused = 0; h.dump_cursor = 0; h.n_big = 0;
     *t.hdr = h;
   }
   if (i < cap) {
@@ -188,7 +188,7 @@ static IntegrateScratch scratch_carve(void* base, size_t max_rec) {
 }
 
 __global__ void tsdf_begin_kernel(TsdfHeader* h) {
-  h->n_records = 0; h->n_touched = 0; h->seg_cursor = 0; h->fused = 0;
+  h->n_records = 0; h->n_touched = 0; h->seg_cursor = 0; h->fused = 0; h->n_big = 0;
 }
 
 // one thread per point: global_volume.py:51-71
@@ -313,20 +313,76 @@ __global__ __launch_bounds__(256) void tsdf_replay_kernel(void* base, uint64_t c
     }
     for (uint32_t r = 0; r < L; r++) apply(sp[r]);
   } else {
-    long long last = -1;
-    for (uint32_t r = 0; r < L; r++) {
-      // selection: smallest sequence number greater than the last one applied
-      uint32_t best = 0xFFFFFFFFu, bj = 0;
-      for (uint32_t j = 0; j < L; j++) {
-        const uint32_t sv = S.seg_seq[o + j];
-        if ((long long)sv > last && sv < best) { best = sv; bj = j; }
-      }
-      last = best;
-      apply(bj);
-    }
+    // a voxel close to the camera collects hundreds of samples of one keyframe: handed to tsdf_replay_big_kernel (one
+    // wave per voxel)
+    S.rec_slot[atomicAdd(&t.hdr->n_big, 1u)] = slot;   // rec_slot is dead after the scatter pass
+    return;
   }
   t.tsdf[slot] = tsdf; t.weight[slot] = weight; t.state[slot] = state;
   t.cnt[slot] = 0; t.fill[slot] = 0;
+}
+
+// one WAVE per voxel with more than kSortMax samples: the lanes rank the sequence numbers (all distinct) against each
+// other in LDS - O(L^2 / 64) compares per lane instead of O(L^2) global re-reads by one thread - and stage the samples in
+// that order; lane 0 then applies the running update (sequential by definition).  Segments longer than kBigMax fall
+// back to the selection scan.
+constexpr uint32_t kBigMax = 2048;
+
+__global__ __launch_bounds__(64) void tsdf_replay_big_kernel(void* base, uint64_t cap, IntegrateScratch S,
+                                                             double max_weight) {
+  __shared__ uint32_t b_seq[kBigMax];
+  __shared__ float b_tsdf[kBigMax];
+  __shared__ double b_w[kBigMax];
+  TsdfTable t = table_carve(base, cap);
+  const uint32_t n_big = t.hdr->n_big;
+  const int lane = threadIdx.x;
+  for (uint32_t v = blockIdx.x; v < n_big; v += gridDim.x) {
+    const uint32_t slot = S.rec_slot[v];
+    const uint32_t L = t.cnt[slot], o = t.off[slot];
+    double tsdf = t.tsdf[slot], weight = t.weight[slot];
+    uint8_t state = t.state[slot];
+    auto apply = [&](double tv, double w) {
+      if (state == 0) {
+        tsdf = tv; weight = w; state = 1;
+      } else {
+        double total = weight + w;
+        if (total > max_weight) total = max_weight;
+        tsdf = (tsdf * weight + tv * w) / (total > 1.0e-9 ? total : 1.0e-9);
+        weight = total;
+        state = 2;
+      }
+    };
+    if (L <= kBigMax) {
+      for (uint32_t r = lane; r < L; r += 64) b_seq[r] = S.seg_seq[o + r];
+      __syncthreads();
+      for (uint32_t r = lane; r < L; r += 64) {
+        const uint32_t mine = b_seq[r];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < L; j++) rank += b_seq[j] < mine ? 1u : 0u;
+        b_tsdf[rank] = S.seg_tsdf[o + r];
+        b_w[rank] = S.seg_w[o + r];
+      }
+      __syncthreads();
+      if (lane == 0)
+        for (uint32_t r = 0; r < L; r++) apply((double)b_tsdf[r], b_w[r]);
+    } else if (lane == 0) {
+      long long last = -1;
+      for (uint32_t r = 0; r < L; r++) {
+        uint32_t best = 0xFFFFFFFFu, bj = 0;
+        for (uint32_t j = 0; j < L; j++) {
+          const uint32_t sv = S.seg_seq[o + j];
+          if ((long long)sv > last && sv < best) { best = sv; bj = j; }
+        }
+        last = best;
+        apply((double)S.seg_tsdf[o + bj], S.seg_w[o + bj]);
+      }
+    }
+    if (lane == 0) {
+      t.tsdf[slot] = tsdf; t.weight[slot] = weight; t.state[slot] = state;
+      t.cnt[slot] = 0; t.fill[slot] = 0;
+    }
+    __syncthreads();   // the LDS arrays are reused by the next voxel of this wave
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -579,6 +635,7 @@ extern "C" int mslam_tsdf_integrate(void* table, uint64_t capacity, const float*
   hipLaunchKernelGGL(tsdf_alloc_kernel, dim3(rec_blocks), dim3(256), 0, s, table, capacity, S);
   hipLaunchKernelGGL(tsdf_scatter_kernel, dim3(rec_blocks), dim3(256), 0, s, table, capacity, S, (uint32_t)max_rec);
   hipLaunchKernelGGL(tsdf_replay_kernel, dim3(rec_blocks), dim3(256), 0, s, table, capacity, S, max_weight);
+  hipLaunchKernelGGL(tsdf_replay_big_kernel, dim3(2048), dim3(64), 0, s, table, capacity, S, max_weight);
   MSLAM_LAUNCH_CHECK("tsdf_integrate");
   return MSLAM_OK;
 }
