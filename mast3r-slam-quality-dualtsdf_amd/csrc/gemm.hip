@@ -13,6 +13,7 @@ int launch_gemm_t128(const GemmArgs& a, int waves, int stages, hipStream_t s);
 int launch_gemm_t128x64(const GemmArgs& a, int stages, hipStream_t s);
 int launch_gemm_t256(const GemmArgs& a, int bn, hipStream_t s);
 int launch_gemm_t192(const GemmArgs& a, hipStream_t s);
+int launch_gemm_t256w8(const GemmArgs& a, hipStream_t s);
 
 // Per-shape tile choices for plain (non-conv, ungrouped) problems: the measured table below, editable at run time
 // through mslam_gemm_tile_override (tools/insitu_tune.py finds the entries by timing whole network stages).
@@ -155,6 +156,7 @@ static int launch_gemm_impl(const GemmArgs& a, hipStream_t stream) {
     case 2128: return launch_gemm_t256(a, 128, stream);
     case 2256: return launch_gemm_t256(a, 256, stream);
     case 2192: return launch_gemm_t192(a, stream);
+    case 2258: return launch_gemm_t256w8(a, stream);
     default: MSLAM_REQUIRE(false, "gemm: unknown configuration %d", cfg);
   }
 }

@@ -115,6 +115,7 @@ class SlamSystem:
         self.frame_group = max(1, int(frame_group))
         self.enc_stream = torch.cuda.Stream(device=self.device) if self.frame_group > 1 else None
         self._enc_hi = 0
+        self._kf_value, self._kf_slope = None, None      # keyframe-rule value of the last tracked frame, its decay per frame
         # decode_ahead = k > 0: the NEXT group's pair decode is issued on a stream of its own as soon as at most k
         # already decoded frames are left in front of the current one, so that it runs beside the per-frame matching /
         # tracking of the current group instead of in front of the next group's first frame (more rows are decoded
@@ -172,6 +173,7 @@ class SlamSystem:
                 add_new_kf, _, try_reloc = self.tracker.track(frame)
                 if try_reloc:
                     self.mode = Mode.RELOC
+                self._note_keyframe_rule(add_new_kf or try_reloc)
             elif mode == Mode.RELOC:                    # main.py:375-385
                 X, C = mu.mast3r_inference_mono(self.model, frame)
                 frame.update_pointmap(X, C)
@@ -245,6 +247,28 @@ class SlamSystem:
         self._worker.q.put((idx, ev))
 
     # ------------------------------------------------------------------ frame groups
+    def _note_keyframe_rule(self, changed):
+        """Bookkeeping for the size of the next speculative decode: the value the keyframe rule compares with its
+        threshold (tracker.py:170-177) falls steadily while the camera moves away from the keyframe; its decay per frame
+        says how many more frames the keyframe is likely to last."""
+        v = self.tracker.last_kf_value
+        if changed or v is None:
+            self._kf_value = None
+            return
+        if self._kf_value is not None:
+            d = max(self._kf_value - v, 0.0)
+            self._kf_slope = d if self._kf_slope is None else 0.5 * self._kf_slope + 0.5 * d
+        self._kf_value = v
+
+    def _speculative_window(self, B):
+        """Frames worth decoding against the current keyframe in one call: all B right behind a keyframe change, fewer
+        when the keyframe rule is about to fire (rows decoded against a keyframe that is replaced are wasted; results do
+        not depend on the grouping)."""
+        if self._kf_value is None or not self._kf_slope or self._kf_slope <= 0.0:
+            return B
+        left = (self._kf_value - config["tracking"]["match_frac_thresh"]) / self._kf_slope
+        return max(1, min(B, int(left)))
+
     def _wait_encoded(self, frame, stream=None, keep=False):
         ev = getattr(frame, "enc_event", None)
         if ev is not None:
@@ -297,7 +321,7 @@ class SlamSystem:
             lo = h + 1                                   # few left: the next group, beside this one's tracking
         else:
             return
-        window = [frames[k] for k in range(lo, min(n, lo + B))]
+        window = [frames[k] for k in range(lo, min(n, lo + self._speculative_window(B)))]
         for f in window:
             if getattr(f, "decoded", None) is not None:  # decoded against a keyframe that has been replaced since
                 self.stats["void_rows"] += 1

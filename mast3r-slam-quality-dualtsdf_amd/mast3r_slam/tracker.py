@@ -22,6 +22,7 @@ class FrameTracker:
         self._ws = None
         self._status = None
         self.quality_service = None
+        self.last_kf_value = None
 
     def reset_idx_f2k(self):
         self.idx_f2k = None
@@ -92,6 +93,7 @@ class FrameTracker:
         self.keyframes[len(self.keyframes) - 1] = keyframe
 
         match_frac_k, unique_frac_f = float(verdict[3]), float(verdict[4])
+        self.last_kf_value = min(match_frac_k, unique_frac_f)     # how far the keyframe rule is from firing
         new_kf = min(match_frac_k, unique_frac_f) < self.cfg["match_frac_thresh"]
         if new_kf:
             self.reset_idx_f2k()
