@@ -199,6 +199,69 @@ def isolated_dominant_us(L, m, M, N, K, dev, iters=50):
     return 1e3 * e0.elapsed_time(e1) / iters
 
 
+def hbm_kernel_probes(ses, dev):
+    """The HBM-bound kernels of the step, each alone on the GPU on one full-resolution room pair, event-timed: algorithmic
+    bytes (SURVEY §8d / DESIGN.md per-unit figures) / launch time against the 8 TB/s HBM peak.  Isolated, after the clock
+    has stopped (inside the loop their launches are a few per frame and share the chip with the network)."""
+    import mast3r_slam_backends as be
+    from mast3r_slam import matching
+    from mast3r_slam.config import config
+
+    room = ses.model.room
+    ki, kj = torch.tensor([3.0], device=dev), torch.tensor([0.0], device=dev)
+    a, b = room.pair_fused(ki, kj)
+    mc = config["matching"]
+    rays, pts, p0 = matching.prep_for_iter_proj(a["pts3d"], b["pts3d"], None)
+    D11 = a["desc"].half().contiguous()
+    D21 = b["desc"].reshape(1, H * W, -1).half().contiguous()
+    p_new, conv = be.iter_proj(rays, pts, p0, mc["max_iter"], mc["lambda_init"], mc["convergence_thresh"])
+    p1 = p_new.long().contiguous()
+
+    def timed(fn, n=20):
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / n
+
+    out = []
+    def add(name, nbytes, us):
+        out.append({"kernel": name, "algorithmic_bytes": nbytes, "us_per_launch_isolated": us,
+                    "achieved_GBps": nbytes / us * 1e-3, "frac_of_8TBps": nbytes / us * 1e-3 / PEAK_HBM_GBS})
+    add("prep_iter_proj_kernel (rays + gradients, 1 pair direction)", H * W * (24 + 36 + 12 + 8),
+        timed(lambda: matching.prep_for_iter_proj(a["pts3d"], b["pts3d"], None)))
+    add("iter_proj_kernel (1 pair direction)", 12.8e6,
+        timed(lambda: be.iter_proj(rays, pts, p0, mc["max_iter"], mc["lambda_init"], mc["convergence_thresh"])))
+    add("refine_matches_kernel<24> (1 pair direction; bound by its sequential IEEE-half add chain)", 25.2e6,
+        timed(lambda: be.refine_matches(D11, D21, p1, mc["radius"], mc["dilation_max"])))
+    # GN edge kernels on a small graph at full resolution
+    from mast3r_slam import synthetic
+
+    g = synthetic.make_graph(n_kf=3, h=H, w=W, seed=3, stride=3, extra_edges=1)
+    d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in g.items() if isinstance(v, np.ndarray)}
+    E = int(d["ii"].numel())
+    valid_pts = float(d["valid_match"].float().sum())
+    lc = config["local_opt"]
+    blk = lambda: be.gn_blocks("rays", d["Twc"], d["Xs"], d["Cs"], None, d["ii"], d["jj"], d["idx_ii2jj"], d["valid_match"],
+                               d["Q"], lc["sigma_ray"], lc["sigma_dist"], lc["C_conf"], lc["Q_conf"])
+    t_once = timed(blk, 10)       # begin + compact + one accumulate + reduce
+    full = lambda it: be.gauss_newton_rays(d["Twc"].clone(), d["Xs"], d["Cs"], d["ii"], d["jj"], d["idx_ii2jj"],
+                                           d["valid_match"], d["Q"], lc["sigma_ray"], lc["sigma_dist"], lc["C_conf"],
+                                           lc["Q_conf"], it, lc["delta_norm"])
+    t1, t9 = timed(lambda: full(1), 5), timed(lambda: full(9), 5)
+    per_it = (t9 - t1) / 8.0       # accumulate + solve of one iteration of this tiny graph
+    add(f"gn_compact + gn_accum + reduce, first pass ({E} directed edges: launch-latency bound at this size)",
+        E * H * W * 45.0 + valid_pts * 32.0, t_once)
+    add(f"gn_accum_kernel per iteration incl. the 14-unknown solve ({E} directed edges, {valid_pts / (E * H * W):.2f} of the points "
+        "survive; latency bound at this size - at 980 edges the kernel streams 4.1 TB/s, profiles/r02_gn_125kf_kernel_stats.csv)",
+        valid_pts * 28.0, per_it)
+    return out
+
+
 def cpu_baseline(args, graph_kfs, graph_edges, edges_per_kf, kf_every):
     """The oracle (kind = "port") timed on the host cores for a BOUNDED sample of the same workload:
     one tracked frame (torch-CPU fp32 network restatement + C matching + numpy tracking GN) plus one
@@ -354,6 +417,7 @@ def main():
     kf1, e1 = ses.graph()
     st1 = dict(ses.system.stats)
     iso_us = isolated_dominant_us(L, mslam_hip, M, N, K, dev) if not args.no_network else 0.0
+    hbm = hbm_kernel_probes(ses, dev)
     enc_rows, dec_rows = ses.model.enc_rows - rows0[0], ses.model.dec_rows - rows0[1]
     if world > 1:
         import torch.distributed as dist
@@ -413,7 +477,8 @@ def main():
                          "method": "HIP events around every launch of this shape inside the timed region, on its launch stream "
                                    "(mslam_gemm_profile_begin/end)",
                          "network_tflops_over_timed_region": gflop / (1e3 * elapsed) if elapsed > 0 else 0.0,
-                         "network_gflop_per_step": gflop / args.steps},
+                         "network_gflop_per_step": gflop / args.steps,
+                         "hbm_bound_kernels": hbm},
         }
         if not args.no_cpu_baseline:
             kfs_mean = max(2, (kf0 + kf1) // 2)

@@ -109,6 +109,7 @@ class SlamSystem:
         self._lock = threading.RLock()
         self._hand = {"main": None, "backend": None}   # event at the end of each side's last critical section
         self._commits = []                              # (solve job, event): optimised poses waiting to be written back
+        self._backend_done = None                       # event behind the last backend task (threaded backend)
         self._worker = _BackendThread(self) if backend == "thread" else None
         self.mode = Mode.INIT
         self.last_T = None
@@ -162,6 +163,7 @@ class SlamSystem:
         mode = self.mode
         if mode == Mode.RELOC and self._worker is not None:
             self._worker.drain()                        # relocalisation edits the factor graph: the backend must be idle
+            self._adopt_backend_tensors()
         with self._critical("main"):
             self._apply_commits(wait=(mode == Mode.RELOC))
             if mode == Mode.INIT:                       # main.py:359-367
@@ -196,6 +198,18 @@ class SlamSystem:
             self._worker.drain()
             with self._critical("main"):
                 self._apply_commits(wait=True)
+
+    def _adopt_backend_tensors(self):
+        """Relocalisation (main.py:28-71) edits and solves the factor graph on the TRACKING stream, but its tensors were
+        allocated and last written on the backend stream: the tracking stream first waits for everything the (now idle)
+        backend thread has enqueued, and the caching allocator is told that these blocks are in use on this stream too."""
+        main = torch.cuda.current_stream(self.device)
+        if self._backend_done is not None:
+            main.wait_event(self._backend_done)
+        fg = self.factor_graph
+        for t in (fg.ii, fg.jj, fg.idx_ii2jj, fg.idx_jj2ii, fg.valid_match_j, fg.valid_match_i, fg.Q_ii2jj, fg.Q_jj2ii):
+            if t.is_cuda and t.numel():
+                t.record_stream(main)
 
     def _apply_commits(self, wait=False):
         """Threaded backend: the global GN runs on copies, outside the hand-over lock; its poses are written into the
@@ -382,6 +396,9 @@ class SlamSystem:
             torch.cuda.current_stream(self.device).synchronize()   # outside the lock: the refiner reads scalars back
             with self._critical("backend"):
                 self._refine(idx)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self._backend_done = done
 
     def _refine(self, idx):
         if self.tsdf_refiner is not None:      # main.py:403-421, after the backend task of the keyframe
