@@ -21,8 +21,14 @@ namespace mslam {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) short short8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 constexpr int BK = 64;
+// Measurement builds only (tools/probes/build_gemm_ablate.sh): 1 = no DMA behind the prologue (MFMA + fragment reads +
+// barriers), 2 = no MFMA (DMA + waits + barriers + fragment reads), 3 = no fragment reads (MFMA on stale registers).
+#ifndef MSLAM_GEMM_ABLATE
+#define MSLAM_GEMM_ABLATE 0
+#endif
 constexpr unsigned kOob = 0x80000000u;  // byte offset beyond any buffer (all operands are < 2 GiB): reads as zero
 
 #define MSLAM_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -172,6 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
   const int nk = (g.K + BK - 1) / BK;
   // issue tile `kt` into ring stage `st` (tiles are issued in increasing kt order, exactly once each)
   auto issue = [&](int st, int kt) {
+    if (MSLAM_GEMM_ABLATE == 1 && kt >= S - 1) return;
     unsigned char* sbase = smem + st * STAGE + wid * 1024;
     const int k0 = kt * BK;
     // Validity is folded into the offset with sign-bit arithmetic (bit 31 set = out of range = zero fill).
@@ -230,9 +237,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
       for (int k = 0; k < KG; k++) {
         const int so = ((2 * (kg + k)) ^ kh) * 16;
 #pragma unroll
-        for (int mi = 0; mi < MI; mi++) af[k][mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 4096 + so);
+        for (int mi = 0; mi < MI; mi++) {
+          if (MSLAM_GEMM_ABLATE == 3) af[k][mi] = __builtin_bit_cast(bf16x8, u32x4_t{(unsigned)so, 1u, 2u, 3u});
+          else af[k][mi] = *reinterpret_cast<const bf16x8*>(sA + mi * 4096 + so);
+        }
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++) bfr[k][ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 4096 + so);
+        for (int ni = 0; ni < NI; ni++) {
+          if (MSLAM_GEMM_ABLATE == 3) bfr[k][ni] = __builtin_bit_cast(bf16x8, u32x4_t{(unsigned)so, 5u, 6u, 7u});
+          else bfr[k][ni] = *reinterpret_cast<const bf16x8*>(sB + ni * 4096 + so);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler would re-serialise them)
 #pragma unroll
@@ -244,8 +257,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
             af[k][mi] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(short8, af[k][mi]), z));
           }
 #pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][mi], bfr[k][ni], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NI; ni++) {
+            if (MSLAM_GEMM_ABLATE == 2) {   // keep the fragments alive without the matrix instruction
+              asm volatile("" ::"v"(af[k][mi]), "v"(bfr[k][ni]));
+            } else {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][mi], bfr[k][ni], acc[mi][ni], 0, 0, 0);
+            }
+          }
         }
       }
       if (kg + KG < KS) __builtin_amdgcn_sched_barrier(0);

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmslam_hip.so")
+LIB_PATH = os.environ.get("MSLAM_LIB", os.path.join(_HERE, "libmslam_hip.so"))   # MSLAM_LIB: measurement builds (tools/probes)
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float

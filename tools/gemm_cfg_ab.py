@@ -13,6 +13,7 @@ ap.add_argument("shapes", nargs="+")
 ap.add_argument("--cfgs", type=int, nargs="+", default=[0, 2256, 2192, 1282])
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--no-check", action="store_true", help="skip the correctness check (ablation builds: MSLAM_LIB=...)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 L = m.lib()
@@ -30,7 +31,7 @@ for sh in a.shapes:
         out.zero_()
         L.mslam_gemm_bf16(m.ptr(A), m.ptr(Wt), m.ptr(bias), 0, m.ptr(out), M, N, K, act, 1, m.stream_ptr())
         err = (out[:256].float() - ref).abs().max().item() / ref.abs().max().item()
-        assert err < 2e-2, (c, err)
+        assert a.no_check or err < 2e-2, (c, err)
     for r in range(a.rounds):
         for c in a.cfgs:
             L.mslam_gemm_tile_override(M, N, K, c)
