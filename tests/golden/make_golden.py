@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block  refine_schedule  evaluate  dataloader
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block  refine_schedule  retrieval_quantize  evaluate  dataloader
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -1122,6 +1122,40 @@ def section_refine_schedule():
 
 
 SECTIONS["refine_schedule"] = section_refine_schedule
+
+
+def section_retrieval_quantize():
+    """RetrievalDatabase.quantize_custom (retrieval_database.py:96-105): the method's own source (taken from the file's
+    AST: the module cannot be imported without asmk) run on a seeded random codebook (65 536 x 1024) and 768 seeded
+    features, multiple_assignment 5 (query) and 1 (build).  Only the indices and the seeds are stored; the test
+    regenerates the inputs."""
+    import ast
+    import textwrap
+
+    src = open(f"{REF}/mast3r_slam/retrieval_database.py").read()
+    fn = [n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "quantize_custom"][0]
+    code = textwrap.dedent(ast.get_source_segment(src, fn))
+    ns = {"torch": torch}
+    exec(code, ns)
+
+    class Self:
+        pass
+
+    g = torch.Generator().manual_seed(1234)
+    me = Self()
+    me.centroids = torch.randn(65536, 1024, generator=g)
+    q = torch.randn(768, 1024, generator=g)
+    q[:64] = me.centroids[1000:1064] + 0.05 * torch.randn(64, 1024, generator=g)      # some features sit near a centroid
+    out = {}
+    for name, k in (("query", 5), ("build", 1)):
+        out[name] = ns["quantize_custom"](me, q, {"quantize": {"multiple_assignment": k}}).numpy()
+    d = torch.cdist(q[:8], me.centroids)
+    out["gap_check"] = torch.topk(d, 6, dim=1, largest=False).values.numpy()
+    print("retrieval_quantize", out["query"][:3], out["query"][64:66])
+    np.savez_compressed(os.path.join(HERE, "retrieval_quantize.npz"), seed=np.array(1234), **out, **meta())
+
+
+SECTIONS["retrieval_quantize"] = section_retrieval_quantize
 SECTIONS["utils_wrappers"] = section_utils_wrappers
 SECTIONS["track_logic"] = section_track_logic
 SECTIONS["factor_graph"] = section_factor_graph
