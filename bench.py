@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--decode-ahead", type=int, default=0,
                     help="SlamSystem decode_ahead: issue the next group's pair decode on its own stream when at most this "
                          "many decoded frames are left (0: on the tracking stream when none is left)")
+    ap.add_argument("--tracking-priority", type=int, default=0,
+                    help="run the tracking loop on a stream of this priority (-1 = high) instead of the default stream")
     ap.add_argument("--no-tsdf", action="store_true", help="debug: global + local TSDF off")
     ap.add_argument("--no-network", action="store_true", help="debug: geometry stand-in only, no network launches")
     ap.add_argument("--depth-scale", type=float, default=1.0, help="debug: <1 shrinks the encoder depth")
@@ -162,7 +164,14 @@ class Session:
         self.pos = 0
 
     def run(self, n):
-        self.system.run(self.frames, self.pos, self.pos + n, release=True)
+        if self.args.tracking_priority != 0:
+            if not hasattr(self, "_trk_stream"):
+                self._trk_stream = torch.cuda.Stream(device=self.dev, priority=self.args.tracking_priority)
+                self._trk_stream.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(self._trk_stream):
+                self.system.run(self.frames, self.pos, self.pos + n, release=True)
+        else:
+            self.system.run(self.frames, self.pos, self.pos + n, release=True)
         self.pos += n
 
     def drain(self):

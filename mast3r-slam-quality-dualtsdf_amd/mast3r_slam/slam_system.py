@@ -274,14 +274,16 @@ class SlamSystem:
             self._kf_slope = d if self._kf_slope is None else 0.5 * self._kf_slope + 0.5 * d
         self._kf_value = v
 
-    def _speculative_window(self, B):
+    def _speculative_window(self, B, already=0):
         """Frames worth decoding against the current keyframe in one call: all B right behind a keyframe change, fewer
         when the keyframe rule is about to fire (rows decoded against a keyframe that is replaced are wasted; results do
-        not depend on the grouping)."""
+        not depend on the grouping).  `already` = frames in front of the call that are decoded but not tracked yet
+        (look-ahead calls): they use up part of what the keyframe is expected to last."""
         if self._kf_value is None or not self._kf_slope or self._kf_slope <= 0.0:
-            return B
+            return B if already == 0 else 0      # nothing known yet: no speculation beyond the current group
         left = (self._kf_value - config["tracking"]["match_frac_thresh"]) / self._kf_slope
-        return max(1, min(B, int(left)))
+        n = min(B, int(left) - already)
+        return max(1, n) if already == 0 else max(0, n)
 
     def _wait_encoded(self, frame, stream=None, keep=False):
         ev = getattr(frame, "enc_event", None)
@@ -335,7 +337,9 @@ class SlamSystem:
             lo = h + 1                                   # few left: the next group, beside this one's tracking
         else:
             return
-        window = [frames[k] for k in range(lo, min(n, lo + self._speculative_window(B)))]
+        window = [frames[k] for k in range(lo, min(n, lo + self._speculative_window(B, lo - i)))]
+        if not window:
+            return
         for f in window:
             if getattr(f, "decoded", None) is not None:  # decoded against a keyframe that has been replaced since
                 self.stats["void_rows"] += 1

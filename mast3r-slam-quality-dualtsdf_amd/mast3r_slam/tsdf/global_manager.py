@@ -71,18 +71,15 @@ class TSDFGlobalIntegrator:
     def _integrate_snapshot(self, snap):
         if snap is None:
             return
-
-        class frame:   # the three tensors of the snapshot under the names used below
-            X_canon, C, T_WC = snap[0], snap[1], Sim3(snap[2])
-
-        points = frame.X_canon.detach().reshape(-1, 3)
-        conf = frame.C.detach().reshape(-1)
+        X_canon, C, T_data = snap
+        points = X_canon.reshape(-1, 3)
+        conf = C.reshape(-1)
         valid_idx = torch.nonzero(conf > self.min_conf).view(-1)
         if valid_idx.numel() == 0:
             return
         count = min(valid_idx.numel(), self.max_points)
         choice = valid_idx[torch.randperm(valid_idx.numel(), device=valid_idx.device)[:count]]
-        pose = Sim3(frame.T_WC.data.clone())
+        pose = Sim3(T_data)
         pts_world = pose.act(points[choice].contiguous())
         cam_origin = pose.act(torch.zeros(1, 3, device=points.device, dtype=points.dtype)).squeeze(0)
         self.volume.integrate(pts_world, conf[choice].double(), cam_origin, return_fused=False)
