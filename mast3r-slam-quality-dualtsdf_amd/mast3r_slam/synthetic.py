@@ -122,7 +122,7 @@ def project(K, X):
 
 
 def make_graph(n_kf=4, h=24, w=32, stride=8, extra_edges=2, seed=0, pose_noise=0.01, point_noise=0.0,
-               n_frames=1000):
+               n_frames=1000, pairs=None):
     """A small factor graph in the reference's layout (global_opt.py:106-121): keyframes every
     `stride` frames, edges (k-1,k) plus `extra_edges` random earlier ones, BOTH directions
     (prep_two_way_edges).  Correspondences are geometric nearest pixels with an occlusion test.
@@ -139,6 +139,8 @@ def make_graph(n_kf=4, h=24, w=32, stride=8, extra_edges=2, seed=0, pose_noise=0
     for k in range(2, n_kf):
         for m in rng.choice(k - 1, size=min(extra_edges, k - 1), replace=False):
             und.append((int(m), k))
+    if pairs is not None:      # explicit undirected keyframe pairs instead of chain + random earlier ones
+        und = [(int(a), int(b)) for a, b in pairs]
     ii = np.array([a for a, b in und] + [b for a, b in und], np.int64)
     jj = np.array([b for a, b in und] + [a for a, b in und], np.int64)
     E = len(ii)

@@ -288,3 +288,38 @@ def test_compaction_gates(device):
                               d["valid_match"], d["Q"], sa, sb, 1.8, 2.4, height=48, width=64, pixel_border=3,
                               z_eps=1e-6)
         assert _rel(Hs.cpu().numpy(), Hr) <= 1e-5 and _rel(gs.cpu().numpy(), gr) <= 1e-5
+
+
+def test_hub_keyframe_with_many_neighbours(device):
+    """A keyframe connected to 44 others (a revisited place): its block row of the normal equations has more column
+    blocks than the assemble kernel's LDS table holds (32), so the rest go through the read-modify-write path.  Solver
+    checked on identical blocks against the oracle's assemble + dense LL^T, and end to end."""
+    import mast3r_slam_backends as be
+
+    h, w, n_kf = 12, 16, 46
+    pairs = [(k - 1, k) for k in range(1, n_kf)] + [(0, k) for k in range(2, n_kf)]
+    g, d = _graph(device, n_kf=n_kf, h=h, w=w, seed=8, stride=1, pose_noise=0.004, pairs=pairs)
+    Hs, gs = be.gn_blocks("rays", d["Twc"], d["Xs"], d["Cs"], None, d["ii"], d["jj"], d["idx_ii2jj"], d["valid_match"],
+                          d["Q"], 0.003, 10.0, 0.0, 1.5)
+    uniq, ie, je, io, jo = oracle.edge_rows(g["ii"], g["jj"])
+    # hub = keyframe 0 is the pinned one: its row is dropped; make keyframe 1 a hub too by pinning order: use jo/io as is
+    dx_same, failed = oracle.gn_solve(Hs.cpu().numpy(), gs.cpu().numpy(), io, jo, n_kf - 1)
+    assert not failed
+    Twc = d["Twc"].clone()
+    dx = _gn_call(be, "rays", Twc, d, h, w, 0.003, 10.0, 1, 1e-8).cpu().numpy()
+    assert np.abs(dx - dx_same).max() <= 1e-6 * max(np.abs(dx_same).max(), 1.0)
+    # the same with the hub NOT pinned (global ids reversed: the hub gets the largest id, i.e. the last block row)
+    g2 = dict(g, ii=g["ii"].max() - g["ii"], jj=g["jj"].max() - g["jj"])
+    order = np.argsort(np.unique(np.concatenate((g2["ii"], g2["jj"]))))    # rows follow the sorted ids: reverse the stacks
+    Twc2, Xs2, Cs2 = g["Twc"][::-1].copy(), g["Xs"][::-1].copy(), g["Cs"][::-1].copy()
+    d2 = {k: _t(v, device) for k, v in dict(Twc=Twc2, Xs=Xs2, Cs=Cs2, ii=g2["ii"], jj=g2["jj"], idx_ii2jj=g["idx_ii2jj"],
+                                            valid_match=g["valid_match"], Q=g["Q"]).items()}
+    Hs2, gs2 = be.gn_blocks("rays", d2["Twc"], d2["Xs"], d2["Cs"], None, d2["ii"], d2["jj"], d2["idx_ii2jj"],
+                            d2["valid_match"], d2["Q"], 0.003, 10.0, 0.0, 1.5)
+    _, _, _, io2, jo2 = oracle.edge_rows(g2["ii"], g2["jj"])
+    assert (np.bincount(np.concatenate((io2[io2 >= 0], jo2[jo2 >= 0]))).max() // 2) >= 44    # a row with 44+ neighbours
+    dx_same2, failed2 = oracle.gn_solve(Hs2.cpu().numpy(), gs2.cpu().numpy(), io2, jo2, n_kf - 1)
+    assert not failed2
+    T2 = d2["Twc"].clone()
+    dx2 = _gn_call(be, "rays", T2, d2, h, w, 0.003, 10.0, 1, 1e-8).cpu().numpy()
+    assert np.abs(dx2 - dx_same2).max() <= 1e-6 * max(np.abs(dx_same2).max(), 1.0)
