@@ -4,7 +4,7 @@ box; only these small .npz data files do.  Usage:
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [section ...]
 
-Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block  refine_schedule  retrieval_quantize  evaluate  dataloader
+Sections: prep  tracker  tsdf_global  tsdf_refine  network  resize  geometry  quality  frame  factor_graph  track_logic  utils_wrappers  refine_block  refine_schedule  retrieval_quantize  retrieval_asmk  evaluate  dataloader
 Every fixture records numpy/torch versions (the global TSDF arithmetic depends on NumPy's
 promotion rules: the container has NumPy 2.x (NEP 50), the reference pins numpy==1.26.4).
 """
@@ -1156,6 +1156,142 @@ def section_retrieval_quantize():
 
 
 SECTIONS["retrieval_quantize"] = section_retrieval_quantize
+
+def _ref_asmk_modules():
+    """The reference's own asmk modules (thirdparty/mast3r/asmk/asmk/{kernel,inverted_file,functional,io_helpers}.py) with
+    its Cython extension built by oracle/Makefile's `ref` target into oracle/_ref/asmk_ext (asmk/__init__.py itself pulls
+    faiss through asmk_method -> index, so the package object is made here and the four modules are loaded under it)."""
+    import types
+
+    ext = os.path.join(ROOT, "oracle", "_ref", "asmk_ext")
+    sys.path.insert(0, ext)
+    import hamming
+
+    pkg = types.ModuleType("asmk")
+    pkg.__path__ = [f"{REF}/thirdparty/mast3r/asmk/asmk"]
+    sys.modules["asmk"] = pkg
+    sys.modules["asmk.hamming"] = hamming
+    pkg.hamming = hamming
+    from asmk import functional, inverted_file, io_helpers, kernel
+
+    return hamming, kernel, inverted_file, functional, io_helpers
+
+
+def section_retrieval_asmk():
+    """RetrievalDatabase.update / query / add_to_database / accumulate_scores / add_to_ivf_custom / prep_features
+    (retrieval_database.py:24-166; the methods' own source from the file's AST - the module needs faiss and torchvision to
+    import) driving the reference's ASMKKernel + IVF + compiled hamming extension, with Whitener / how_select_local taken
+    the same way from thirdparty/mast3r/mast3r/retrieval/model.py.  Small seeded sizes: backbone dim 32, 48 tokens,
+    descriptor dim 64, 24 local features per image, 512 centroids, 12 images of which three revisit earlier ones."""
+    import ast
+    import textwrap
+    import types
+
+    hamming, kernel, inverted_file, functional, io_helpers = _ref_asmk_modules()
+    msrc = open(f"{REF}/thirdparty/mast3r/mast3r/retrieval/model.py").read()
+    mtree = ast.parse(msrc)
+    ns_model = {"torch": torch, "nn": torch.nn, "np": np}
+    for node in mtree.body:
+        if (isinstance(node, ast.ClassDef) and node.name == "Whitener") or \
+           (isinstance(node, ast.FunctionDef) and node.name == "how_select_local"):
+            exec(ast.get_source_segment(msrc, node), ns_model)
+    Whitener, how_select_local = ns_model["Whitener"], ns_model["how_select_local"]
+
+    src = open(f"{REF}/mast3r_slam/retrieval_database.py").read()
+    cls = [n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.ClassDef) and n.name == "RetrievalDatabase"][0]
+    ns = {"torch": torch, "np": np, "io_helpers": io_helpers, "how_select_local": how_select_local}
+    body = "\n".join(textwrap.dedent(ast.get_source_segment(src, f)) for f in cls.body
+                     if isinstance(f, ast.FunctionDef) and f.name != "__init__")
+    exec(body, ns)
+    RefDB = type("RefDB", (), {k: v for k, v in ns.items() if isinstance(v, types.FunctionType) and k != "how_select_local"})
+
+    g = torch.Generator().manual_seed(77)
+    BD, NT, D, NF, K, NIMG = 32, 48, 64, 24, 512, 12
+    model = types.SimpleNamespace()
+    model.prewhiten = Whitener(BD)
+    model.postwhiten = Whitener(D)
+    with torch.no_grad():
+        model.prewhiten.m.copy_(0.1 * torch.randn(1, BD, generator=g, dtype=torch.float64))
+        model.prewhiten.p.copy_(torch.eye(BD, dtype=torch.float64) + 0.2 * torch.randn(BD, BD, generator=g, dtype=torch.float64))
+        model.postwhiten.m.copy_(0.1 * torch.randn(1, D, generator=g, dtype=torch.float64))
+        model.postwhiten.p.copy_(torch.eye(D, dtype=torch.float64) + 0.2 * torch.randn(D, D, generator=g, dtype=torch.float64))
+    lin = torch.nn.Linear(BD, D)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(D, BD, generator=g) / BD ** 0.5)
+        lin.bias.copy_(0.05 * torch.randn(D, generator=g))
+    model.projector = torch.nn.Sequential(lin)         # build_projector(hdims=[D]) (model.py:139-151)
+    model.residual = False
+    model.attention = lambda x: x.norm(dim=-1)         # featweights == 'l2norm' (model.py:131-132)
+    model.nfeat = NF
+    centroids = torch.randn(K, D, generator=g).numpy().astype(np.float32)
+    params = {"build_ivf": {"kernel": {"binary": True}, "ivf": {"use_idf": False},          # processor.py:84-89
+                            "quantize": {"multiple_assignment": 1}, "aggregate": {}},
+              "query_ivf": {"quantize": {"multiple_assignment": 5}, "aggregate": {}, "search": {"topk": None},
+                            "similarity": {"similarity_threshold": 0.0, "alpha": 3.0}}}
+    codebook = types.SimpleNamespace(centroids=centroids, size=K)
+    kern = kernel.ASMKKernel(codebook, binary=True)
+    ivf = inverted_file.IVF.initialize_empty(use_idf=False, codebook_size=K)
+    me = RefDB()
+    me.model = model
+    me.asmk = types.SimpleNamespace(params=params, codebook=codebook)
+    me.ivf_builder = types.SimpleNamespace(kernel=kern, ivf=ivf, step_params=params["build_ivf"])
+    me.kf_counter, me.kf_ids = 0, []
+    me.query_dtype, me.query_device = torch.float32, "cpu"
+    me.centroids = torch.from_numpy(centroids)
+
+    feats = torch.randn(NIMG, 1, NT, BD, generator=g)
+    for new, old in ((5, 1), (8, 2), (11, 5)):           # revisits: an earlier frame's tokens, slightly changed
+        feats[new] = feats[old] + 0.05 * torch.randn(1, NT, BD, generator=g)
+    seen = {}
+    orig_query = RefDB.query
+
+    def spy_query(self, feat, id):
+        ranks, scores, topk = orig_query(self, feat, id)
+        seen["ranks"], seen["scores"], seen["topk"] = ranks.copy(), scores.copy(), topk.copy()
+        return ranks, scores, topk
+
+    RefDB.query = spy_query
+    out = {}
+    with torch.no_grad():
+        for i in range(NIMG):
+            frame = types.SimpleNamespace(feat=feats[i])
+            out[f"local_{i}"] = me.prep_features(frame.feat)[0].numpy()
+            inds = me.update(frame, add_after_query=True, k=3, min_thresh=0.005)
+            out[f"inds_{i}"] = np.array(inds, dtype=np.int64)
+            if i > 0:
+                sc = np.empty_like(seen["scores"])
+                sc[np.arange(sc.shape[0])[:, None], seen["ranks"]] = seen["scores"]
+                out[f"scores_{i}"], out[f"topk_{i}"] = sc[0], seen["topk"]
+        probe = types.SimpleNamespace(feat=feats[2] + 0.02 * torch.randn(1, NT, BD, generator=g))
+        out["probe_feat"] = probe.feat.numpy()
+        out["probe_inds"] = np.array(me.update(probe, add_after_query=False, k=4, min_thresh=0.0), dtype=np.int64)   # relocalisation use
+        sc = np.empty_like(seen["scores"])
+        sc[np.arange(sc.shape[0])[:, None], seen["ranks"]] = seen["scores"]
+        out["probe_scores"] = sc[0]
+    assert me.kf_counter == NIMG and ivf.n_images == NIMG
+    words = np.array([w for w in range(K) if ivf.counts[w] > 0], dtype=np.int64)
+    out["ivf_words"] = np.concatenate([np.full(ivf.counts[w], w) for w in words])
+    out["ivf_imids"] = np.concatenate([ivf.ivf_image_ids[w][:ivf.counts[w]] for w in words])
+    out["ivf_vecs"] = np.concatenate([ivf.ivf_vecs[w][:ivf.counts[w]] for w in words])
+    out["norm_factor"] = np.asarray(ivf.norm_factor, dtype=np.float64)
+    print("retrieval_asmk", [out[f"inds_{i}"].tolist() for i in range(NIMG)], out["probe_inds"], out["ivf_vecs"].shape)
+    np.savez_compressed(os.path.join(HERE, "retrieval_asmk.npz"), feats=feats.numpy(), centroids=centroids,
+                        pre_m=model.prewhiten.m.detach().numpy(), pre_p=model.prewhiten.p.detach().numpy(),
+                        post_m=model.postwhiten.m.detach().numpy(), post_p=model.postwhiten.p.detach().numpy(),
+                        proj_w=lin.weight.detach().numpy(), proj_b=lin.bias.detach().numpy(), nfeat=np.array(NF), **out, **meta())
+    # the known answers the reference's own hamming tests / docstrings hold (asmk/test/test_hamming.py, hamming.pyx:60,88,117,135)
+    r = np.random.default_rng(5)
+    kat = {}
+    for d1 in (1, 7, 31, 32, 33, 64, 100, 128, 139):
+        a = (r.random((10, d1)) - 0.5).astype(np.float32)
+        b = (r.random((10, d1)) - 0.5).astype(np.float32)
+        kat[f"a_{d1}"], kat[f"b_{d1}"] = a, b
+        kat[f"pack_a_{d1}"] = hamming.binarize_and_pack_2D(a)
+        kat[f"cdist_{d1}"] = hamming.hamming_cdist_packed(hamming.binarize_and_pack_2D(a), hamming.binarize_and_pack_2D(b), d1)
+    np.savez_compressed(os.path.join(HERE, "asmk_hamming.npz"), **kat, **meta())
+
+
+SECTIONS["retrieval_asmk"] = section_retrieval_asmk
 SECTIONS["utils_wrappers"] = section_utils_wrappers
 SECTIONS["track_logic"] = section_track_logic
 SECTIONS["factor_graph"] = section_factor_graph
