@@ -330,6 +330,29 @@ int mslam_room_pair(const float* ki, const float* kj, int batch, int h, int w, i
                     double cx, double cy, double noise, const double* Wm_3x24, const double* phase_24, float* X1,
                     float* C1, float* D1, float* Q1, float* X2, float* C2, float* D2, float* Q2, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Retrieval database: ASMK with binarised residuals.  Replaces, for one image at a time,
+ *   ASMKKernel.aggregate_image + hamming.binarize_and_pack_2D   (thirdparty/mast3r/asmk/asmk/kernel.py:28-42,
+ *                                                                asmk/cython/hamming.pyx:93-127)
+ *   IVF.search + ASMKKernel.similarity + functional.asmk_kernel (asmk/inverted_file.py:90-114, kernel.py:59-71,
+ *                                                                functional.py:10-15; use_idf False, processor.py:85)
+ * as mast3r_slam/retrieval_database.py:107-166 calls them.
+ *
+ * mslam_asmk_aggregate: des f32[n_des, dim]; centroids f32[n_centroids, dim]; assign i64[n_des, m_assign] (the output
+ *   of quantize_custom); uniq_words i64[n_uniq] = sorted unique values of `assign`; sig_out u32[n_uniq, dim/32]:
+ *   bit (31 - d%32) of word d/32 = (sum of residuals of dimension d > 0).  dim must be a multiple of 32.
+ * mslam_asmk_search: the inverted file as flat arrays in insertion order - entry_word i32[n_entries], entry_sig
+ *   u32[n_entries, sig_words], img_start i32[n_images + 1] (entries of image i are [img_start[i], img_start[i+1]), words
+ *   ascending) - queried with q_words i32[n_q] (sorted, unique) / q_sig u32[n_q, sig_words];
+ *   scores f64[n_images] = sum over shared words of sim^alpha [sim >= threshold] / sqrt(entries of the image), over
+ *   sqrt(n_q); sim = 1 - 2 hamming / (32 sig_words).  Signatures 16-byte aligned when sig_words % 4 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int mslam_asmk_aggregate(const float* des, const float* centroids, const int64_t* assign, const int64_t* uniq_words,
+                         uint32_t* sig_out, int n_des, int m_assign, int dim, int n_uniq, int n_centroids, void* stream);
+int mslam_asmk_search(const int32_t* entry_word, const uint32_t* entry_sig, const int32_t* img_start, int n_images,
+                      const int32_t* q_words, const uint32_t* q_sig, int n_q, int sig_words, float similarity_threshold,
+                      float alpha, double* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,6 @@
 """Mirror of the reference's mast3r_slam/mast3r_utils.py (lines 14-278): same function names, argument
 order and return tuples; the model object is mast3r_slam.mast3r_model.Mast3rHIP and matching is
-mast3r_slam.matching (both libmslam_hip.so).  Retrieval (load_retriever) is out of scope."""
+mast3r_slam.matching (both libmslam_hip.so); the retrieval database is mast3r_slam.retrieval_database."""
 import numpy as np
 import torch
 
@@ -13,6 +13,16 @@ def load_mast3r(path=None, device="cuda"):
     """mast3r_utils.py:14-21."""
     weights_path = "checkpoints/MASt3R_ViTLarge_BaseDecoder_512_catmlpdpt_metric.pth" if path is None else path
     return Mast3rHIP(load_mast3r_state_dict(weights_path), Mast3rConfig(), device=device)
+
+
+def load_retriever(mast3r_model, retriever_path=None, device="cuda"):
+    """mast3r_utils.py:24-31.  The backbone argument is kept for the signature: the database only ever consumes
+    `frame.feat` (retrieval_database.py:24-41), never the encoder itself."""
+    from mast3r_slam.retrieval_database import RetrievalDatabase
+
+    retriever_path = ("checkpoints/MASt3R_ViTLarge_BaseDecoder_512_catmlpdpt_metric_retrieval_trainingfree.pth"
+                      if retriever_path is None else retriever_path)
+    return RetrievalDatabase.from_checkpoint(retriever_path, device=device)
 
 
 def _hw(shape):

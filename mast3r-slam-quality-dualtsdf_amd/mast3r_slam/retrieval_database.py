@@ -1,16 +1,28 @@
-"""The compute part of mast3r_slam/retrieval_database.py that does not need ASMK: `quantize_custom`
-(lines 96-105) - nearest `multiple_assignment` codebook centroids of every local feature by L2 distance, the
-(n x d) . (d x 64k) distance GEMM + top-k the reference runs in fp32 torch.
+"""Mirror of mast3r_slam/retrieval_database.py (lines 9-166): the keyframe retrieval database - MASt3R retrieval head
+(whitening, projector, attention top-k), ASMK with binarised residuals over a 64k codebook, incremental inverted file -
+with the same methods (`prep_features`, `update`, `query`, `add_to_database`, `quantize_custom`) and the same results,
+resident on the device.
 
-The rest of the class (prep_features: whitening / attention of the retrieval model; ASMK aggregate, inverted file,
-Hamming-kernel search) needs the `asmk` package, the retrieval checkpoint and its codebook, none of which is available
-offline; `RetrievalDatabase` below therefore takes those parts as injected objects with the reference's call signatures
-and only implements what is ours.  SlamSystem accepts any object with `update(frame, add_after_query, k, min_thresh)`.
+What runs where
+  * `quantize_custom` (lines 96-105): the (n x d) . (d x 64k) distance GEMM + top-k on the bf16 MFMA GEMM
+    (csrc/gemm_kernel.h) in fp32 quality - hi/lo split of both operands (three products, ~2^-16 relative) ranks a
+    candidate set of k + 16 centroids per feature, whose distances are then recomputed in fp32 exactly as the reference
+    forms them; index-exact against the reference unless two centroids are closer than fp32 rounding.
+  * aggregation + binarisation (asmk kernel.py:28-42, hamming.pyx:93-127) and the inverted-file search with the Hamming
+    kernel (inverted_file.py:90-114, kernel.py:59-71, functional.py:10-15): csrc/retrieval.hip.  The reference keeps a
+    python list of numpy arrays per visual word and walks the query's words in a python loop; here the file is three
+    flat device arrays in insertion order (word id, 1024-bit signature, image offsets) and one launch scores every
+    database image (a block per image, its entries summed in the reference's order, so scores agree to the last bit of
+    the fp64 accumulation apart from the rounding of sim^3).
+  * `prep_features` (lines 24-41): two fp64 whitening GEMMs and the fp32 projector on rocBLAS through torch (plain
+    library GEMMs, 768 x 1024 x 1024), attention = row norm, top-`nfeat` rows.
 
-On the matrix cores in fp32 quality: the bf16 GEMM (csrc/gemm_kernel.h) is run on a hi/lo split of both operands
-(q = q_hi + q_lo, three products hi.hi + hi.lo + lo.hi, fp32 accumulate: ~2^-16 relative), which ranks a candidate set of
-k + 16 centroids per feature; their distances are then recomputed in fp32 exactly as the reference forms them and the
-final top-k is taken from those - index-exact against the reference unless two centroids are closer than fp32 rounding."""
+The retrieval checkpoint and its codebook pickle are not available offline: `RetrievalDatabase.from_checkpoint` follows
+thirdparty/mast3r/mast3r/retrieval/processor.py:64-98 for whoever has the files; tests and the synthetic runs construct the
+class from tensors (`RetrievalWeights`, a codebook).  SlamSystem accepts any object with
+`update(frame, add_after_query, k, min_thresh)`."""
+import os
+
 import torch
 
 import mslam_hip as _m
@@ -57,23 +69,182 @@ class CentroidIndex:
         return torch.gather(cand, 1, order)
 
 
-class RetrievalDatabase:
-    """retrieval_database.py:9-166 with the ASMK-dependent parts injected (`prep_features`, `kernel`, `ivf`, `params`
-    as the reference's `Retriever` / `asmk` objects provide them)."""
+ASMK_PARAMS = {     # thirdparty/mast3r/mast3r/retrieval/processor.py:84-89
+    "build_ivf": {"kernel": {"binary": True}, "ivf": {"use_idf": False}, "quantize": {"multiple_assignment": 1},
+                  "aggregate": {}},
+    "query_ivf": {"quantize": {"multiple_assignment": 5}, "aggregate": {}, "search": {"topk": None},
+                  "similarity": {"similarity_threshold": 0.0, "alpha": 3.0}},
+}
 
-    def __init__(self, centroids, prep_features=None, asmk_params=None, ivf_builder=None, device="cuda"):
+
+class RetrievalWeights:
+    """The retrieval head of thirdparty/mast3r/mast3r/retrieval/model.py:108-151 without its backbone: `prewhiten` /
+    `postwhiten` = (m (1, d) f64, p (d, d') f64) or None (nn.Identity), `projector` = list of Linear layers
+    (weight, bias[, ln_weight, ln_bias]) - every layer but the last is followed by LayerNorm + GELU (build_projector) -
+    `residual`, `nfeat`."""
+
+    def __init__(self, prewhiten, projector, postwhiten, nfeat=300, residual=False, device="cuda"):
+        f64 = lambda t: None if t is None else tuple(torch.as_tensor(x).to(device=device, dtype=torch.float64) for x in t)
+        self.prewhiten, self.postwhiten = f64(prewhiten), f64(postwhiten)
+        self.projector = [tuple(torch.as_tensor(x).to(device=device, dtype=torch.float32) for x in layer) for layer in projector]
+        self.nfeat, self.residual = nfeat, bool(residual)
+
+    @classmethod
+    def from_state_dict(cls, sd, nfeat, residual, device="cuda"):
+        """Keys of RetrievalModel.state_dict(): prewhiten.m/p, projector.<i>.weight/bias, postwhiten.m/p."""
+        wh = lambda k: (sd[f"{k}.m"], sd[f"{k}.p"]) if f"{k}.m" in sd else None
+        ids = sorted({int(k.split(".")[1]) for k in sd if k.startswith("projector.")})
+        lin = [i for i in ids if sd[f"projector.{i}.weight"].ndim == 2]
+        layers = []
+        for i in lin:
+            layer = [sd[f"projector.{i}.weight"], sd[f"projector.{i}.bias"]]
+            if f"projector.{i + 1}.weight" in sd and sd[f"projector.{i + 1}.weight"].ndim == 1:
+                layer += [sd[f"projector.{i + 1}.weight"], sd[f"projector.{i + 1}.bias"]]
+            layers.append(tuple(layer))
+        return cls(wh("prewhiten"), layers, wh("postwhiten"), nfeat=nfeat, residual=residual, device=device)
+
+
+def _whiten(x, mp):
+    """Whitener.forward (retrieval/model.py:62-77, l2norm None): fp64 centre + matmul, cast back to the input type."""
+    if mp is None:
+        return x
+    m, p = mp
+    out = torch.matmul(x.reshape(-1, x.shape[-1]).to(torch.float64) - m, p)
+    return out.reshape(x.shape[:-1] + (p.shape[1],)).to(x.dtype)
+
+
+class RetrievalDatabase:
+    """retrieval_database.py:9-166.  `weights`: RetrievalWeights; `centroids`: the ASMK codebook (K, d) f32."""
+
+    def __init__(self, weights, centroids, asmk_params=None, device="cuda"):
         self.query_device = device
-        self.index = CentroidIndex(centroids.to(device))
+        self.query_dtype = torch.float32
+        self.weights = weights
+        self.index = CentroidIndex(torch.as_tensor(centroids).to(device))
         self.centroids = self.index.centroids
-        self._prep, self.params, self.ivf_builder = prep_features, asmk_params, ivf_builder
+        self.params = asmk_params or ASMK_PARAMS
+        if self.params["build_ivf"]["ivf"]["use_idf"] or not self.params["build_ivf"]["kernel"]["binary"]:
+            raise ValueError("only the reference's configuration is built: binary signatures, no idf (processor.py:85)")
+        dim = int(self.centroids.shape[1])
+        if dim % 32:
+            raise ValueError(f"descriptor dimension {dim} is not a multiple of 32")
+        self.sig_words = dim // 32
+        # the inverted file: flat arrays in insertion order, grown by doubling
+        self._cap = 0
+        self._e_word = torch.zeros(0, dtype=torch.int32, device=device)
+        self._e_sig = torch.zeros((0, self.sig_words), dtype=torch.int32, device=device)      # uint32 bit patterns
+        self._starts = [0]                               # host mirror of img_start
+        self._img_start = torch.zeros(1, dtype=torch.int32, device=device)
         self.kf_counter = 0
         self.kf_ids = []
+        self.last_scores = None
+
+    @classmethod
+    def from_checkpoint(cls, modelname, device="cuda"):
+        """thirdparty/mast3r/mast3r/retrieval/processor.py:64-98: `<name>.pth` = {'args': Namespace, 'model': state_dict},
+        `<name minus its last _field>_codebook.pkl` = Codebook.state_dict() (asmk/codebook.py:67-78).  Files supplied by the
+        user (they are not part of the reference tree); loaded the way the reference loads them."""
+        import pickle
+
+        assert os.path.isfile(modelname), modelname
+        ckpt = torch.load(modelname, "cpu", weights_only=False)
+        a = ckpt["args"]
+        dname, bname = os.path.split(modelname)
+        cb = os.path.join(dname, "_".join(bname.split("_")[:-1]) + "_codebook.pkl")
+        assert os.path.isfile(cb), cb
+        with open(cb, "rb") as fh:
+            centroids = pickle.load(fh)["state"]["centroids"]
+        w = RetrievalWeights.from_state_dict(ckpt["model"], nfeat=a.nfeat, residual=getattr(a, "residual", False), device=device)
+        return cls(w, torch.from_numpy(centroids), device=device)
+
+    @property
+    def n_images(self):
+        return len(self._starts) - 1
+
+    # -------------------------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def prep_features(self, backbone_feat):
+        """:24-41 (retrieval/model.py:205-216 without the encoder; how_select_local :89-105)."""
+        w = self.weights
+        x = _whiten(backbone_feat.to(self.query_device), w.prewhiten)
+        proj = x
+        for li, layer in enumerate(w.projector):
+            proj = torch.nn.functional.linear(proj, layer[0], layer[1])
+            if li + 1 < len(w.projector):
+                proj = torch.nn.functional.gelu(torch.nn.functional.layer_norm(proj, proj.shape[-1:], layer[2], layer[3]))
+        if w.residual:
+            proj = proj + x
+        attention = proj.norm(dim=-1)
+        post = _whiten(proj, w.postwhiten)
+        nfeat = w.nfeat
+        nfeat = int(-nfeat * post.size(1)) if nfeat < 0 else int(nfeat)
+        idx = torch.topk(attention, min(nfeat, attention.size(1)), dim=1).indices
+        return torch.gather(post, 1, idx.unsqueeze(-1).expand(-1, -1, post.size(2)))
 
     def quantize_custom(self, qvecs, params):
-        """retrieval_database.py:96-105 -> indices (n, multiple_assignment) int64."""
+        """:96-105 -> indices (n, multiple_assignment) int64."""
         return self.index.nearest(qvecs.to(self.query_device), int(params["quantize"]["multiple_assignment"]))
 
+    def _aggregate(self, des, codes):
+        """kernel.py:28-42: (signatures u32 bit patterns (U, W) as int32, sorted unique words int64 (U,))."""
+        codes = codes.contiguous()
+        uniq = torch.unique(codes)                                   # sorted; its length is read by the host here
+        sig = torch.empty((uniq.numel(), self.sig_words), dtype=torch.int32, device=des.device)
+        rc = _m.lib().mslam_asmk_aggregate(_m.ptr(des), _m.ptr(self.centroids), _m.ptr(codes), _m.ptr(uniq), _m.ptr(sig),
+                                           des.shape[0], codes.shape[1], des.shape[1], uniq.numel(),
+                                           self.centroids.shape[0], _m.stream_ptr())
+        _m.check(rc, "asmk_aggregate")
+        return sig, uniq
+
+    @torch.inference_mode()
+    def query(self, feat, id=None):
+        """:77-93 + accumulate_scores :107-137.  `feat`: local descriptors (n, d) of ONE image.  Returns (scores f64
+        (n_images,) in image order, topk codes (n, multiple_assignment)) - the reference's (ranks, ranked scores) pair is
+        this vector sorted, and `update` (:58-62) undoes the sorting first thing."""
+        q = self.params["query_ivf"]
+        des = feat.to(self.query_device, torch.float32).contiguous()
+        topk = self.quantize_custom(des, q)
+        sig, uniq = self._aggregate(des, topk)
+        scores = torch.zeros(self.n_images, dtype=torch.float64, device=des.device)
+        rc = _m.lib().mslam_asmk_search(_m.ptr(self._e_word), _m.ptr(self._e_sig), _m.ptr(self._img_start), self.n_images,
+                                        _m.ptr(uniq.to(torch.int32)), _m.ptr(sig), uniq.numel(), self.sig_words,
+                                        float(q["similarity"]["similarity_threshold"]), float(q["similarity"]["alpha"]),
+                                        _m.ptr(scores), _m.stream_ptr())
+        _m.check(rc, "asmk_search")
+        return scores, topk
+
+    @torch.inference_mode()
+    def add_to_database(self, feat, id=None, topk_codes=None):
+        """:95-101 + add_to_ivf_custom :139-166 + IVF.add (inverted_file.py:61-88)."""
+        des = feat.to(self.query_device, torch.float32).contiguous()
+        b = self.params["build_ivf"]
+        kb = int(b["quantize"]["multiple_assignment"])
+        codes = self.quantize_custom(des, b) if topk_codes is None else topk_codes[:, :kb]
+        sig, uniq = self._aggregate(des, codes)
+        n0, n1 = self._starts[-1], self._starts[-1] + uniq.numel()
+        if n1 > self._cap:
+            cap = max(4096, 2 * self._cap, n1)
+            ew = torch.zeros(cap, dtype=torch.int32, device=des.device)
+            es = torch.zeros((cap, self.sig_words), dtype=torch.int32, device=des.device)
+            ew[:n0], es[:n0] = self._e_word[:n0], self._e_sig[:n0]
+            self._e_word, self._e_sig, self._cap = ew, es, cap
+        self._e_word[n0:n1] = uniq.to(torch.int32)
+        self._e_sig[n0:n1] = sig
+        self._starts.append(n1)
+        self._img_start = torch.tensor(self._starts, dtype=torch.int32, device=des.device)
+        self.kf_ids.append(self.kf_counter)
+        self.kf_counter += 1
+
+    @torch.inference_mode()
     def update(self, frame, add_after_query, k, min_thresh=0.0):
-        raise RuntimeError("RetrievalDatabase.update needs the asmk package, the retrieval checkpoint and its codebook "
-                           "(aggregate / inverted file / Hamming search, retrieval_database.py:43-166); none is available "
-                           "offline - pass SlamSystem another retriever (e.g. synthetic_gpu.PoseProximityRetriever)")
+        """:43-75."""
+        feat = self.prep_features(frame.feat)[0]                     # one frame at a time, as the reference assumes
+        topk_image_inds, topk_codes = [], None
+        if self.kf_counter > 0:
+            scores, topk_codes = self.query(feat)
+            self.last_scores = scores
+            top = torch.topk(scores, min(k, self.n_images))
+            topk_image_inds = top.indices[top.values > min_thresh].tolist()
+        if add_after_query:
+            self.add_to_database(feat, None, topk_codes)
+        return topk_image_inds

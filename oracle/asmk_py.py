@@ -136,11 +136,15 @@ class RetrievalDatabase:
 
     def update(self, feat, add_after_query, k, min_thresh=0.0):
         """:43-75; `feat` = frame.feat (1, tokens, backbone dim)."""
-        local = prep_features(feat, self.w)[0]
+        return self.update_local(prep_features(feat, self.w)[0], add_after_query, k, min_thresh)
+
+    def update_local(self, local, add_after_query, k, min_thresh=0.0, codes=None):
+        """The same from the local descriptors on (`codes`: optional precomputed quantize() output with the query's
+        multiple assignment, for tests that pin the later stages on identical assignments)."""
         inds, topk_codes = [], None
         if self.kf_counter > 0:
             q = self.params["query_ivf"]
-            topk_codes = quantize(local, self.centroids, q["quantize"]["multiple_assignment"])
+            topk_codes = quantize(local, self.centroids, q["quantize"]["multiple_assignment"]) if codes is None else codes
             ades, uniq = aggregate_image(local, topk_codes, self.centroids)
             scores = self.ivf.search(ades, uniq, **q["similarity"])
             self.last_scores = scores
@@ -149,8 +153,9 @@ class RetrievalDatabase:
             inds = [int(i) for i in order if scores[i] > min_thresh]
         if add_after_query:
             kb = self.params["build_ivf"]["quantize"]["multiple_assignment"]
-            codes = quantize(local, self.centroids, kb) if topk_codes is None else topk_codes[:, :kb]
-            ades, uniq = aggregate_image(local, codes, self.centroids)
+            if topk_codes is None:
+                topk_codes = quantize(local, self.centroids, kb) if codes is None else codes
+            ades, uniq = aggregate_image(local, topk_codes[:, :kb], self.centroids)
             self.ivf.add(ades, uniq, np.full(len(uniq), self.kf_counter, dtype=np.int64))
             self.kf_ids.append(self.kf_counter)
             self.kf_counter += 1
