@@ -67,6 +67,10 @@ def parse():
                          "0.5 gives a keyframe every ~8 frames, the rate BASELINE config 3 names (the reference default 0.333 "
                          "would give one every ~40)")
     ap.add_argument("--retrieval-k", type=int, default=3)
+    ap.add_argument("--retriever", choices=("pose", "asmk"), default="pose",
+                    help="loop-closure proposals: 'pose' = the pose-proximity stand-in (what a trained retrieval model would "
+                         "return on this scene); 'asmk' = the product's RetrievalDatabase (mast3r_slam/retrieval_database.py) "
+                         "with a random retrieval head and a random 64k x 1024 codebook on the random-weight encoder's tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks on cuda:0 with gloo collectives (rehearses the N>1 code path on a one-GPU box)")
@@ -141,6 +145,14 @@ class Session:
         self.model = RoomGeometryModel(self.net, dev, H, W, n_frames=self.n_path, seed=rank)
         path_index = lambda fr: self.base + args.stride * int(fr.frame_id)
         retriever = PoseProximityRetriever(path_index, self.n_path)
+        if args.retriever == "asmk":
+            from mast3r_slam.retrieval_database import RetrievalDatabase, RetrievalWeights
+
+            g = torch.Generator().manual_seed(1000 + rank)
+            eye = torch.eye(1024, dtype=torch.float64)
+            wh = lambda: (torch.zeros(1, 1024, dtype=torch.float64), eye + 0.02 * torch.randn(1024, 1024, generator=g, dtype=torch.float64))
+            rw = RetrievalWeights(wh(), [(torch.randn(1024, 1024, generator=g) / 32.0, torch.zeros(1024))], wh(), nfeat=300, device=dev)
+            retriever = RetrievalDatabase(rw, torch.randn(65536, 1024, generator=g), device=dev)
         tg = tr = qs = None
         if not args.no_tsdf:
             # pre_icp_iters / max_iterations 0: the reference's TSDF pose refinement steps along the UNIT gradient with the
@@ -460,7 +472,8 @@ def main():
             "config": {"workload": "synthetic 512x384 RGB-D stream through the product loop (SlamSystem.run): tracked frame "
                                    f"every step, real keyframe decisions ({new_kf} new keyframes in the timed {args.steps} steps), "
                                    f"backend per keyframe over the whole graph: {kf0}->{kf1} keyframes, {e0}->{e1} undirected "
-                                   f"edges ({2 * e1} directed) incl. retrieval k={args.retrieval_k}, 40k-point global TSDF fuse + "
+                                   f"edges ({2 * e1} directed) incl. retrieval k={args.retrieval_k} "
+                                   f"({'pose-proximity stand-in' if args.retriever == 'pose' else 'ASMK RetrievalDatabase, random head + codebook'}), 40k-point global TSDF fuse + "
                                    "budgeted re-fusion (TSDF pose refinement off: the reference's step overshoots 8x and "
                                    "breaks tracking on this scene), local TSDF block refinement"
                                    + (f"; {preroll} frames pre-rolled untimed so that the graph has the mean size of the "

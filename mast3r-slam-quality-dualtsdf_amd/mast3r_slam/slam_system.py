@@ -219,7 +219,11 @@ class SlamSystem:
             job, ev = self._commits[0]
             if not wait and not ev.query():
                 return
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(ev)
+            for t in job.values():      # allocated on the backend's stream, read here on this one: without the note the
+                if torch.is_tensor(t) and t.is_cuda:   # caching allocator hands the block back to the backend the moment
+                    t.record_stream(main)              # the job is dropped, while this stream's copy is still queued
             self.factor_graph.commit_solve(job)
             self._commits.pop(0)
 

@@ -132,7 +132,8 @@ def test_published_sizes_against_the_oracle(device):
     np.testing.assert_array_equal(np.diff(db._starts), np.bincount(ref.ivf.imids))
 
 
-def test_slam_system_with_the_retrieval_database(device, monkeypatch):
+@pytest.mark.parametrize("backend", ["inline", "thread"])
+def test_slam_system_with_the_retrieval_database(device, monkeypatch, backend):
     """The product loop with the retrieval class in the retriever slot.  The stand-in encoder writes a smooth code of the
     camera-path position into the tokens (random retrieval head and codebook on top), the camera goes out and comes back:
     on the way back the database must propose keyframes from the way out, and the factor graph must gain loop edges
@@ -159,7 +160,7 @@ def test_slam_system_with_the_retrieval_database(device, monkeypatch):
     db = RetrievalDatabase(w, torch.randn(K, D, generator=gen) * 0.7, device=device)
     ks = list(range(0, 63, 3)) + list(range(60, -3, -3))
     torch.manual_seed(0)
-    system = SlamSystem(PlaceModel(device), device, retriever=db, frame_group=1)
+    system = SlamSystem(PlaceModel(device), device, retriever=db, frame_group=1, backend=backend)
     frames = _frames(ks, device)
     system.run(frames)
     system.shutdown()

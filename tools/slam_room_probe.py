@@ -27,6 +27,20 @@ if os.environ.get("PROBE_NET"):
 model = RoomGeometryModel(net, dev, H, W)
 ret = PoseProximityRetriever(lambda fr: stride * int(fr.frame_id), max_dist=float(os.environ.get("PROBE_RDIST", 1.2)),
                              min_cos=float(os.environ.get("PROBE_RCOS", 0.75)))
+if os.environ.get("PROBE_RETR") == "asmk":      # the product's retrieval database, random head + random codebook
+    from mast3r_slam.retrieval_database import RetrievalDatabase, RetrievalWeights
+    g = torch.Generator().manual_seed(1000)
+    eye = torch.eye(1024, dtype=torch.float64)
+    wh = lambda: (torch.zeros(1, 1024, dtype=torch.float64), eye + 0.02 * torch.randn(1024, 1024, generator=g, dtype=torch.float64))
+    rw = RetrievalWeights(wh(), [(torch.randn(1024, 1024, generator=g) / 32.0, torch.zeros(1024))], wh(), nfeat=300, device=dev)
+    ret = RetrievalDatabase(rw, torch.randn(65536, 1024, generator=g), device=dev)
+    _upd = ret.update
+    def _spy(frame, add_after_query, k, min_thresh=0.0):
+        out = _upd(frame, add_after_query, k, min_thresh)
+        sc = None if ret.last_scores is None else np.round(np.sort(ret.last_scores.cpu().numpy())[::-1][:4], 4).tolist()
+        print(f"  retrieval: frame {int(frame.frame_id)} (path {stride * int(frame.frame_id)}) add={int(add_after_query)} -> db ids {out}, best scores {sc}", flush=True)
+        return out
+    ret.update = _spy
 config["retrieval"]["k"] = int(os.environ.get("PROBE_K", 3))
 tg = tr = qs = None
 if os.environ.get("PROBE_TSDF"):
