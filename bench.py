@@ -72,6 +72,9 @@ def parse():
                          "return on this scene); 'asmk' = the product's RetrievalDatabase (mast3r_slam/retrieval_database.py) "
                          "with a random retrieval head and a random 64k x 1024 codebook on the random-weight encoder's tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="PCIe-inclusive variant (DESIGN.md; never the headline value): the RGB frames wait in pinned host "
+                         "memory and every run() call first uploads its frames on the tracking stream")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks on cuda:0 with gloo collectives (rehearses the N>1 code path on a one-GPU box)")
     ap.add_argument("--graphs", action="store_true", help="replay the network as captured HIP graphs (default: eager)")
@@ -173,9 +176,18 @@ class Session:
             img = self.model.room.rgb(k)
             for j in range(img.shape[0]):
                 self.frames.append(Frame(lo + j, img[j:j + 1].clone(), shp, shp, None))
+        self.host_imgs = None
+        if args.host_frames:
+            self.host_imgs = [f.img.cpu().pin_memory() for f in self.frames]
+            for f in self.frames:
+                f.img = None
         self.pos = 0
 
     def run(self, n):
+        if self.host_imgs is not None:      # H2D inside the timed region, in front of the frames' first use
+            for k in range(self.pos, min(self.pos + n, len(self.frames))):
+                self.frames[k].img = self.host_imgs[k].to(self.dev, non_blocking=True)
+                self.host_imgs[k] = None
         if self.args.tracking_priority != 0:
             if not hasattr(self, "_trk_stream"):
                 self._trk_stream = torch.cuda.Stream(device=self.dev, priority=self.args.tracking_priority)
@@ -476,6 +488,7 @@ def main():
                                    f"({'pose-proximity stand-in' if args.retriever == 'pose' else 'ASMK RetrievalDatabase, random head + codebook'}), 40k-point global TSDF fuse + "
                                    "budgeted re-fusion (TSDF pose refinement off: the reference's step overshoots 8x and "
                                    "breaks tracking on this scene), local TSDF block refinement"
+                                   + ("; frames uploaded from pinned host memory inside the timed region (PCIe-inclusive)" if args.host_frames else "")
                                    + (f"; {preroll} frames pre-rolled untimed so that the graph has the mean size of the "
                                       "1 000-frame schedule" if preroll else "; no pre-roll: the graph grows from the first frame"),
                        "weights": "random-init ViT-L/12+12 MASt3R architecture (no checkpoint offline); geometry from the "
