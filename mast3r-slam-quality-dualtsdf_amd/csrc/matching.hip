@@ -77,17 +77,19 @@ __global__ __launch_bounds__(256) void iter_proj_kernel(
 
   float lambda = lambda_init;
   uint8_t conv = 0;
+  // The reference samples the ray image twice per iteration: all 9 channels at (u, v), then the 3 ray channels at the
+  // trial point.  (u, v) is always either the previous (u, v) or the previous trial point, so its sample is already
+  // known if the trial sample takes the gradient channels along: ONE dependent gather per iteration instead of two
+  // (the loop is a chain of memory round trips at 3 waves per SIMD), same operations on the same values.
+  Bilin s = bilin_setup(img, w, u, v);
+  float r0 = bilin_ch(s, 0), r1 = bilin_ch(s, 1), r2 = bilin_ch(s, 2);
+  float gx0 = bilin_ch(s, 3), gx1 = bilin_ch(s, 4), gx2 = bilin_ch(s, 5);
+  float gy0 = bilin_ch(s, 6), gy1 = bilin_ch(s, 7), gy2 = bilin_ch(s, 8);
+  float rinv = 1.0f / sqrtf(dot3(r0, r1, r2, r0, r1, r2));
+  r0 *= rinv; r1 *= rinv; r2 *= rinv;
+  float e0 = r0 - t0, e1 = r1 - t1, e2 = r2 - t2;
+  float cost = dot3(e0, e1, e2, e0, e1, e2);
   for (int it = 0; it < max_iter; it++) {
-    Bilin s = bilin_setup(img, w, u, v);
-    float r0 = bilin_ch(s, 0), r1 = bilin_ch(s, 1), r2 = bilin_ch(s, 2);
-    const float gx0 = bilin_ch(s, 3), gx1 = bilin_ch(s, 4), gx2 = bilin_ch(s, 5);
-    const float gy0 = bilin_ch(s, 6), gy1 = bilin_ch(s, 7), gy2 = bilin_ch(s, 8);
-
-    float rinv = 1.0f / sqrtf(dot3(r0, r1, r2, r0, r1, r2));
-    r0 *= rinv; r1 *= rinv; r2 *= rinv;
-    float e0 = r0 - t0, e1 = r1 - t1, e2 = r2 - t2;
-    const float cost = dot3(e0, e1, e2, e0, e1, e2);
-
     float A00 = dot3(gx0, gx1, gx2, gx0, gx1, gx2);
     const float A01 = dot3(gx0, gx1, gx2, gy0, gy1, gy2);
     float A11 = dot3(gy0, gy1, gy2, gy0, gy1, gy2);
@@ -104,17 +106,24 @@ __global__ __launch_bounds__(256) void iter_proj_kernel(
     const float v_new = fminf(fmaxf(v + delta_v, 1.0f), vmax);
 
     s = bilin_setup(img, w, u_new, v_new);
-    r0 = bilin_ch(s, 0); r1 = bilin_ch(s, 1); r2 = bilin_ch(s, 2);
-    rinv = 1.0f / sqrtf(dot3(r0, r1, r2, r0, r1, r2));
-    r0 *= rinv; r1 *= rinv; r2 *= rinv;
-    e0 = r0 - t0; e1 = r1 - t1; e2 = r2 - t2;
-    const float new_cost = dot3(e0, e1, e2, e0, e1, e2);
+    float n0 = bilin_ch(s, 0), n1 = bilin_ch(s, 1), n2 = bilin_ch(s, 2);
+    // (unconditionally, also in the last iteration: a branch here splits the 36-byte corner reads into dword loads)
+    const float hx0 = bilin_ch(s, 3), hx1 = bilin_ch(s, 4), hx2 = bilin_ch(s, 5);
+    const float hy0 = bilin_ch(s, 6), hy1 = bilin_ch(s, 7), hy2 = bilin_ch(s, 8);
+    rinv = 1.0f / sqrtf(dot3(n0, n1, n2, n0, n1, n2));
+    n0 *= rinv; n1 *= rinv; n2 *= rinv;
+    const float f0 = n0 - t0, f1 = n1 - t1, f2 = n2 - t2;
+    const float new_cost = dot3(f0, f1, f2, f0, f1, f2);
 
     if (new_cost < cost) {
       u = u_new;
       v = v_new;
       lambda = (float)((double)lambda * 0.1);
       conv = new_cost < cost_thresh;
+      e0 = f0; e1 = f1; e2 = f2;
+      cost = new_cost;
+      gx0 = hx0; gx1 = hx1; gx2 = hx2;
+      gy0 = hy0; gy1 = hy1; gy2 = hy2;
     } else {
       lambda = (float)((double)lambda * 10.0);
       conv = cost < cost_thresh;
@@ -126,6 +135,15 @@ __global__ __launch_bounds__(256) void iter_proj_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // refine_matches: IEEE half accumulate, sequential over k, strict '>' arg-max, dilation 5..1
+//
+// What bounds it (PMC, profiles/r02_pmc_refine_matches.json, 158 us at 384x512): 44 M VALU wave-instructions (59 per
+// candidate: the sequential half chain the reference's results require) keep the VALUs 46 % busy; every 16-byte gather
+// goes to L2 (19.8 M L2 read requests = the whole 2.3 GB of candidate descriptors per launch, L2 hit rate 98.8 %, HBM
+// 27 MB): the working set of a CU's 32 waves between two uses of a line is ~100 KB against 32 KB of L1.  Tried in round
+// 2 and dropped, all bit-identical: walking the candidates row-major with a tie-break on the reference order (lines
+// shared by a wave's 2r+1 row neighbours; 152-160 us, the simultaneous misses are not merged) and staging each wave's
+// strip of D11 in LDS (190-211 us: after the first dilation level every lane has moved up to +-15 px on its own and the
+// strip no longer fits).
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 h16;
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
