@@ -269,7 +269,7 @@ def hbm_kernel_probes(ses, dev):
         timed(lambda: matching.prep_for_iter_proj(a["pts3d"], b["pts3d"], None)))
     add("iter_proj_kernel (1 pair direction)", 12.8e6,
         timed(lambda: be.iter_proj(rays, pts, p0, mc["max_iter"], mc["lambda_init"], mc["convergence_thresh"])))
-    add("refine_matches_kernel<24> (1 pair direction; bound by its sequential IEEE-half add chain)", 25.2e6,
+    add("refine_matches_kernel<24> (1 pair direction; bound by L2 gathers + its sequential IEEE-half add chain, not HBM: profiles/r02_pmc_refine_matches.json)", 25.2e6,
         timed(lambda: be.refine_matches(D11, D21, p1, mc["radius"], mc["dilation_max"])))
     # GN edge kernels on a small graph at full resolution
     from mast3r_slam import synthetic
