@@ -12,6 +12,24 @@ rows = db.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3
                   "group by name order by 3 desc", (t0,)).fetchall()
 tot = sum(r[2] for r in rows)
 print(f"window {win / 1e9:.3f} s: {sum(r[1] for r in rows)} dispatches, kernel time {tot / 1e3:.1f} ms = {100 * tot * 1e3 / win:.1f} % of the window (streams overlap: can exceed 100)")
+# union of the kernel intervals (time with at least one kernel resident), the idle gaps between them, and the
+# concurrency profile (share of the window with exactly k kernels in flight)
+ev = []
+for st, en in db.execute("select start, end from kernels where start >= ? order by start", (t0,)):
+    ev.append((st, 1)); ev.append((en, -1))
+ev.sort()
+depth, last, hist, gaps = 0, t0, {}, []
+for t, dlt in ev:
+    hist[depth] = hist.get(depth, 0) + (t - last)
+    if depth == 0 and t > last:
+        gaps.append(t - last)
+    depth += dlt
+    last = t
+busy = sum(v for k, v in hist.items() if k > 0)
+gaps.sort(reverse=True)
+print(f"at least one kernel resident: {100 * busy / win:.1f} % of the window; idle {100 * hist.get(0, 0) / win:.1f} % in {len(gaps)} gaps "
+      f"(longest {gaps[0] / 1e3 if gaps else 0:.0f} us, mean {sum(gaps) / max(1, len(gaps)) / 1e3:.1f} us); "
+      "kernels in flight -> share: " + ", ".join(f"{k}: {100 * v / win:.1f} %" for k, v in sorted(hist.items())[:8]))
 print("name,calls,total_us,percent,avg_us,min_us")
 for r in rows[:top]:
     print('"%s",%d,%.1f,%.2f,%.2f,%.2f' % (r[0][:120], r[1], r[2], 100 * r[2] / tot, r[3], r[4]))
