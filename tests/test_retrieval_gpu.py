@@ -171,3 +171,30 @@ def test_slam_system_with_the_retrieval_database(device, monkeypatch, backend):
     loops = [(a, b) for a, b in zip(ii, jj) if abs(int(a) - int(b)) > 2]
     assert loops, (ii, jj)                                  # retrieval added non-consecutive edges ...
     assert any(abs(kf_k[a] - kf_k[b]) <= 12 for a, b in loops), [(kf_k[a], kf_k[b]) for a, b in loops]   # ... of the same place
+
+
+def test_from_checkpoint_reads_the_reference_file_layout(device, tmp_path, golden_dir):
+    """`<name>_trainingfree.pth` = {'args': Namespace(nfeat, residual, ...), 'model': RetrievalModel.state_dict()} next to
+    `<name>_codebook.pkl` = Codebook.state_dict() (retrieval/processor.py:64-98, asmk/codebook.py:67-78): files of that
+    layout written here from the fixture's tensors give the same database as constructing it from the tensors."""
+    import argparse
+    import pickle
+    import types
+
+    from mast3r_slam.mast3r_utils import load_retriever
+    from mast3r_slam.retrieval_database import RetrievalDatabase
+
+    g = np.load(os.path.join(golden_dir, "retrieval_asmk.npz"))
+    sd = {"prewhiten.m": torch.from_numpy(g["pre_m"]), "prewhiten.p": torch.from_numpy(g["pre_p"]),
+          "projector.0.weight": torch.from_numpy(g["proj_w"]), "projector.0.bias": torch.from_numpy(g["proj_b"]),
+          "postwhiten.m": torch.from_numpy(g["post_m"]), "postwhiten.p": torch.from_numpy(g["post_p"])}
+    args = argparse.Namespace(nfeat=int(g["nfeat"]), residual=False, nclusters=512, imsize=512)
+    pth = tmp_path / "MASt3R_test_retrieval_trainingfree.pth"
+    torch.save({"args": args, "model": sd}, pth)
+    with open(tmp_path / "MASt3R_test_retrieval_codebook.pkl", "wb") as fh:
+        pickle.dump({"type": "Codebook", "params": {"size": 512}, "state": {"centroids": g["centroids"]}}, fh)
+    db = load_retriever(None, str(pth), device=device)
+    assert isinstance(db, RetrievalDatabase) and db.centroids.shape == (512, 64) and db.weights.nfeat == int(g["nfeat"])
+    feats = torch.from_numpy(g["feats"]).to(device)
+    for i in range(6):
+        assert db.update(types.SimpleNamespace(feat=feats[i]), True, 3, 0.005) == g[f"inds_{i}"].tolist()
