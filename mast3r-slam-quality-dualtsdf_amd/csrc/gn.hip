@@ -455,15 +455,21 @@ __global__ __launch_bounds__(64) void gn_assemble_kernel(const GnState* __restri
                                                          const float* __restrict__ gs,
                                                          const int* __restrict__ ii_opt,
                                                          const int* __restrict__ jj_opt, int E, int N,
-                                                         int np, int ld, double* __restrict__ Haug) {
+                                                         int np, int ld, double* __restrict__ Haug,
+                                                         int* __restrict__ tmin32) {
   if (st->done) return;
   const int br = blockIdx.x;  // block row in [0, N); N = identity padding rows
   const int lane = threadIdx.x;
   const int n = N * 7;
   if (br == N) {
-    for (int r = n + lane; r < np; r += 64) Haug[(size_t)r * ld + r] = 1.0;
+    for (int r = n + lane; r < np; r += 64) {
+      Haug[(size_t)r * ld + r] = 1.0;
+      atomicMin(&tmin32[r >> 5], r);          // a padding row holds its diagonal only
+    }
+    if (lane == 0) tmin32[np >> 5] = 0;        // the rhs row is dense
     return;
   }
+  int cmin = br;                               // smallest unpinned column block of this block row (wave-uniform)
   __shared__ double tab[kTab][49];
   __shared__ int tabcol[kTab];
   int ntab = 0;
@@ -485,6 +491,7 @@ __global__ __launch_bounds__(64) void gn_assemble_kernel(const GnState* __restri
           bacc += (double)gs[((size_t)(blk >> 1) * E + ee) * 7 + lane];
         const int cj = __shfl(cj_l, b, 64);
         if (cj < 0) continue;  // pinned column
+        cmin = min(cmin, cj);
         const double v = lane < 49 ? (double)Hs[((size_t)blk * E + ee) * 49 + lane] : 0.0;
         const unsigned long long hit = __ballot(lane < ntab && tabcol[lane] == cj);
         int slot = hit ? __ffsll((long long)hit) - 1 : -1;
@@ -507,6 +514,7 @@ __global__ __launch_bounds__(64) void gn_assemble_kernel(const GnState* __restri
     if (lane < 49) Haug[(size_t)(7 * br + k7) * ld + 7 * cj + l7] += tab[s][lane];
   }
   if (lane < 7) Haug[(size_t)np * ld + 7 * br + lane] = bacc;
+  if (lane < 7) atomicMin(&tmin32[(7 * br + lane) >> 5], 7 * cmin);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -521,13 +529,19 @@ __global__ __launch_bounds__(64) void gn_assemble_kernel(const GnState* __restri
 // in LDS and solves its own rows X L11^T = A21'.  Nobody writes A11 in this launch (the other
 // workgroups read it): the factor of the diagonal block goes to the side array Ldiag[panel].
 // j0 = -NB is the prologue: no update, only the first panel is finished.
+// Envelope: with the keyframes in temporal order H is a band (consecutive + recent-neighbour edges) plus a few far
+// rows (loop closures), and LL^T fill stays inside each row's envelope [first non-zero column, diagonal].  tmin32[b] =
+// the smallest first column over the rows [32 b, 32 b + 32) (written by gn_assemble).  A tile whose row block or
+// column block starts its envelope behind the panel has a zero panel operand: its workgroup leaves at once (the
+// reference hands the same structure to a sparse LL^T, gn_kernels.cu:57-159).
 // Every global load of a workgroup is issued in ONE phase at its start (the launch is latency-bound:
 // 28 dependent launches per factorisation at 125 keyframes).
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 template <int NB>
 __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st, double* __restrict__ A,
-                                                        double* __restrict__ Ldiag, int np, int ld, int j0) {
+                                                        double* __restrict__ Ldiag, int np, int ld, int j0,
+                                                        const int* __restrict__ tmin32) {
   if (st->done) return;
   constexpr int LS = NB + 2;   // LDS row stride of the panel rows: conflict-free f64 MFMA operand reads
   constexpr int TS = kTile + 1;
@@ -538,6 +552,13 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
   const int r0 = j1 + ti * kTile, c0 = j1 + tj * kTile;
   if (r0 > np || c0 >= np) return;
   const bool has_update = j0 >= 0;
+  {
+    const int last = np >> 5;                  // r0, c0 are multiples of 32; a tile covers two 32-row blocks
+    const int fr = min(tmin32[min(r0 >> 5, last)], tmin32[min((r0 >> 5) + 1, last)]);
+    const int fc = min(tmin32[min(c0 >> 5, last)], tmin32[min((c0 >> 5) + 1, last)]);
+    if (tj != 0 && (fr >= j1 || fc >= j1)) return;   // L_i or L_j of this panel is zero: nothing to subtract
+    if (tj == 0 && fr >= j1 + NB) return;            // ... and nothing in the next panel's columns of these rows either
+  }
   extern __shared__ double sh[];
   double* Li = sh;                        // [64][LS] rows r0.. of panel j0
   double* Lj = sh + kTile * LS;           // [64][LS] rows c0.. of panel j0 (first tile column: rows j1.. = Lp)
@@ -852,6 +873,7 @@ struct GnWorkspace {
   double* Haug;
   double* Ldiag;
   double* xs;
+  int* tmin32;   // envelope of H: first non-zero column of the rows [32 b, 32 b + 32), see chol_step_kernel
   int* counts;
   float* partial;
   float* stream;
@@ -867,7 +889,10 @@ static GnWorkspace gn_carve(void* base, int P, int E, int HW, int local_edges) {
   const int n = N * 7;
   w.np = (int)align_up((size_t)(n > 0 ? n : 1), kTile);
   w.ld = w.np;
-  w.nb = n > 2048 ? 64 : 32;
+  // 32-wide panels at every size: a panel step is latency-bound (~32 us against 105-147 us for a 64-wide one), and with
+  // the envelope skip the extra passes over the trailing matrix cost less than the longer steps (measured at 300-1 250
+  // keyframes, profiles/r02_gn_panel_width.log: 46 vs 66 ms per iteration at 8 743 unknowns)
+  w.nb = 32;
   // split every edge over S workgroups: >= ~1k workgroups per launch, >= 16 points per thread
   int S = E > 0 ? (1024 + E - 1) / E : 1;
   const int s_cap = HW / (256 * 16) > 0 ? HW / (256 * 16) : 1;
@@ -890,6 +915,7 @@ static GnWorkspace gn_carve(void* base, int P, int E, int HW, int local_edges) {
   w.Haug = (double*)take(sizeof(double) * (size_t)(w.np + 1) * w.ld);
   w.Ldiag = (double*)take(sizeof(double) * (size_t)w.np * w.nb);
   w.xs = (double*)take(sizeof(double) * (size_t)w.np);
+  w.tmin32 = (int*)take(sizeof(int) * (size_t)(w.np / 32 + 2));
   w.bytes_fixed = off;
   const size_t L = local_edges > 0 ? (size_t)local_edges : 0;
   w.counts = (int*)take(sizeof(int) * L * S);
@@ -952,7 +978,7 @@ static int launch_cholesky(const GnWorkspace& w, hipStream_t s) {
     const int tiles_r = (w.np - j1 + 1 + kTile - 1) / kTile;           // rows j1..np (np = the rhs row)
     const int tiles_c = j0 < 0 ? 1 : (w.np - j1 + kTile - 1) / kTile;  // prologue: only the panel column
     hipLaunchKernelGGL(chol_step_kernel<NB>, dim3(tiles_c, tiles_r), dim3(256), shmem, s, w.st, w.Haug, w.Ldiag,
-                       w.np, w.ld, j0);
+                       w.np, w.ld, j0, w.tmin32);
   }
   if (w.np <= kBackSmall) {
     hipLaunchKernelGGL(chol_back_small_kernel<NB>, dim3(1), dim3(256), 0, s, w.st, w.Haug, w.Ldiag, w.xs, w.np, w.ld);
@@ -971,9 +997,11 @@ static int launch_solve(const GnWorkspace& w, const float* Hs, const float* gs, 
   const int N = P - 1;
   int rc = check_hip(hipMemsetAsync(w.Haug, 0, sizeof(double) * (size_t)(w.np + 1) * w.ld, s), "Haug memset");
   if (rc) return rc;
+  rc = check_hip(hipMemsetAsync(w.tmin32, 0x7f, sizeof(int) * (size_t)(w.np / 32 + 2), s), "tmin32 memset");
+  if (rc) return rc;
   hipLaunchKernelGGL(gn_assemble_kernel, dim3(N + 1), dim3(64), 0, s, w.st, Hs, gs, w.ii_opt, w.jj_opt, E, N, w.np,
-                     w.ld, w.Haug);
-  rc = w.nb == 64 ? launch_cholesky<64>(w, s) : launch_cholesky<32>(w, s);
+                     w.ld, w.Haug, w.tmin32);
+  rc = launch_cholesky<32>(w, s);
   if (rc) return rc;
   hipLaunchKernelGGL(gn_finish_kernel, dim3(1), dim3(256), 0, s, w.st, w.xs, N, 1, Twc, dx, delta_thresh);
   return check_hip(hipGetLastError(), "gn solve launch");

@@ -248,7 +248,7 @@ def test_config3_graph_sizes(device, kind, n_kf):
 
 @pytest.mark.parametrize("n_kf", [300, 450])
 def test_no_pose_cap(device, n_kf):
-    """Beyond the 417-pose limit of the round-1 solver (and through the 64-wide panel instantiation used above
+    """Beyond the 417-pose limit of the round-1 solver (and through the multi-workgroup back-substitution used above
     2 048 unknowns).  A 450-pose chain has condition number ~1e7, so the fp32 rounding of the edge blocks (which both
     sides share only to 1e-5) is amplified in dx; the solver itself is therefore checked on IDENTICAL blocks - the
     oracle's assemble + dense LL^T (gn_kernels.cu:57-159) fed with the blocks the HIP kernels produced - to 1e-7 of
@@ -323,3 +323,31 @@ def test_hub_keyframe_with_many_neighbours(device):
     T2 = d2["Twc"].clone()
     dx2 = _gn_call(be, "rays", T2, d2, h, w, 0.003, 10.0, 1, 1e-8).cpu().numpy()
     assert np.abs(dx2 - dx_same2).max() <= 1e-6 * max(np.abs(dx_same2).max(), 1.0)
+
+
+@pytest.mark.parametrize("n_kf", [120, 420])
+def test_banded_graph_with_loop_closures(device, n_kf):
+    """The usual SLAM graph - consecutive + two recent neighbours, a loop closure to an early keyframe every 40th -
+    where most 64x64 tiles of the trailing matrix lie outside the rows' envelopes and their workgroups leave without
+    touching the matrix (chol_step_kernel, tmin32): solver on IDENTICAL blocks against the oracle's dense LL^T, with the
+    one-workgroup (120 keyframes) and the per-panel (420) back-substitution."""
+    import mast3r_slam_backends as be
+
+    h, w = 12, 16
+    rng = np.random.default_rng(n_kf)
+    pairs = [(k - 1, k) for k in range(1, n_kf)]
+    for k in range(3, n_kf):
+        pairs += [(k - 2, k), (k - 3, k)]
+        if k % 40 == 0:
+            pairs.append((int(rng.integers(0, k // 3)), k))
+    g, d = _graph(device, n_kf=n_kf, h=h, w=w, seed=6, stride=1, pose_noise=0.004, pairs=pairs)
+    Hs, gs = be.gn_blocks("rays", d["Twc"], d["Xs"], d["Cs"], None, d["ii"], d["jj"], d["idx_ii2jj"], d["valid_match"],
+                          d["Q"], 0.003, 10.0, 0.0, 1.5)
+    uniq, ie, je, io, jo = oracle.edge_rows(g["ii"], g["jj"])
+    dx_same, failed = oracle.gn_solve(Hs.cpu().numpy(), gs.cpu().numpy(), io, jo, n_kf - 1)
+    assert not failed
+    Twc = d["Twc"].clone()
+    dx = _gn_call(be, "rays", Twc, d, h, w, 0.003, 10.0, 1, 1e-8).cpu().numpy()
+    scale = np.abs(dx_same).max()
+    assert np.abs(dx - dx_same).max() <= 1e-6 * max(scale, 1.0), (np.abs(dx - dx_same).max(), scale)
+    np.testing.assert_allclose(Twc.cpu().numpy(), oracle.sim3_retr_rows(dx_same, g["Twc"]), rtol=0, atol=2e-5)

@@ -20,6 +20,9 @@ ap.add_argument("poses", type=int, nargs="+")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--hw", type=int, default=384 * 512)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--graph", choices=("random", "band"), default="random",
+                help="random: consecutive + 3 random earlier keyframes (SURVEY 8d: no structure, the envelope is full); "
+                     "band: consecutive + the 2 before + a loop closure to an early keyframe every 40th (a trajectory)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 HW = args.hw
@@ -27,8 +30,13 @@ for P in args.poses:
     rng = np.random.default_rng(P)
     und = [(k - 1, k) for k in range(1, P)]
     for k in range(2, P):
-        for a in rng.choice(k - 1, size=min(3, k - 1), replace=False):
-            und.append((int(a), k))
+        if args.graph == "random":
+            for a in rng.choice(k - 1, size=min(3, k - 1), replace=False):
+                und.append((int(a), k))
+        else:
+            und += [(k - 2, k)] + ([(k - 3, k)] if k >= 3 else [])
+            if k % 40 == 0:
+                und.append((int(rng.integers(0, max(1, k // 3))), k))
     ii = torch.tensor([a for a, b in und] + [b for a, b in und], device=dev)
     jj = torch.tensor([b for a, b in und] + [a for a, b in und], device=dev)
     E = ii.numel()
