@@ -116,7 +116,8 @@ static int launch_gemm_impl(const GemmArgs& a, hipStream_t stream) {
   // traffic and win as soon as they still cover the chip.
   // MSLAM_GEMM="<cfg>" forces one configuration for experiments:
   //   642/643/644: 64x64 ring 2/3/4; 1262/1263: 128x64 ring 2/3; 1242: 128x128 4 waves; 1282/1283: 128x128 8 waves ring 2/3;
-  //   2128: 256x128 8 waves; 2256: 256x256 16 waves; 2192: 192x256 8 waves
+  //   2128: 256x128 8 waves; 2256: 256x256 16 waves; 2192: 192x256 8 waves; 2258: 256x256 8 waves (A/B only: slower than
+  //   2256 and 2192 on every shape of the table, profiles/r02_gemm_cfg_ab.log)
   static int forced = -2;
   if (forced == -2) {
     const char* e = getenv("MSLAM_GEMM");
