@@ -1,0 +1,36 @@
+"""bench.py's output contract on a short run (a child process, as the driver starts it): ONE JSON line on stdout with the
+keys the driver reads, the roofline object measured live (launches of the dominant shape were timed inside the region),
+the per-kernel HBM entries, and the cpu_baseline object when it is not switched off."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line(device):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "4", "--preroll", "40",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("SLAM frames/sec") and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 4 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6          # frames/s = 1 / (s per step) at N = 1
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert r["launches_timed"] > 0 and r["us_per_launch_avg"] >= r["us_per_launch_min"] > 0      # measured inside the timed region
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert abs(r["achieved"] - r["gflop_per_launch"] * 1e3 / r["us_per_launch_avg"]) < 1e-6 * r["achieved"]
+    assert {h["kernel"].split(" ")[0] for h in r["hbm_bound_kernels"]} >= {"prep_iter_proj_kernel", "iter_proj_kernel",
+                                                                           "refine_matches_kernel<24>"}
+    st = d["config"]["stats"]
+    assert st["relocalised"] == 0 and st["keyframes"] >= 2 and st["encoder_rows"] >= 8
+    assert "cpu_baseline" not in d                                                              # switched off above
