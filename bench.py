@@ -515,7 +515,7 @@ def main():
                          "network_gflop_per_step": gflop / args.steps,
                          "hbm_bound_kernels": hbm},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the host baseline is reported on rank 0 at N = 1 only
             kfs_mean = max(2, (kf0 + kf1) // 2)
             edges_mean = max(1, (e0 + e1) // 2)
             out["cpu_baseline"] = cpu_baseline(args, kfs_mean, edges_mean, max(1.0, new_e / max(1, new_kf)),
