@@ -34,3 +34,28 @@ def test_bench_line(device):
     st = d["config"]["stats"]
     assert st["relocalised"] == 0 and st["keyframes"] >= 2 and st["encoder_rows"] >= 8
     assert "cpu_baseline" not in d                                                              # switched off above
+
+
+def test_bench_two_ranks_on_one_card(device):
+    """The N > 1 path as the driver launches it (torch.distributed.run, one process per rank), rehearsed on one card:
+    --share-gpu puts both ranks on cuda:0 with gloo collectives.  Rank 0 prints the one line; the value is the
+    whole-job aggregate (both sessions' frames over the slowest rank's time); the rank count the collective library
+    reports is in the line; no cpu_baseline at N > 1."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4",
+           "--preroll", "40", "--share-gpu"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 8 / 1e3)) < 1e-6 * d["value"]      # two sessions' frames / max time
+    assert "2 rank(s) reported by the collective library" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d
