@@ -93,6 +93,25 @@ def parse():
     return ap.parse_args()
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """The collective libraries print a banner (RCCL: version / hostname / library path, gloo: peer connections) on
+    STDOUT when a communicator is created; the contract is ONE JSON line there, so file descriptor 1 points at stderr
+    while the process group comes up."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,13 +120,18 @@ def dist_setup(args):
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.share_gpu:   # rehearsal of the multi-rank path on one card: every rank on cuda:0, gloo collectives
-            local = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        with stdout_to_stderr():
+            if args.share_gpu:   # rehearsal of the multi-rank path on one card: every rank on cuda:0, gloo collectives
+                local = 0
+                torch.cuda.set_device(0)
+                dist.init_process_group("gloo")
+            else:
+                torch.cuda.set_device(local)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            warm = torch.ones(1, device=torch.device("cuda", local))   # communicators are created by the first collective
+            dist.all_reduce(warm)
+            dist.barrier()
+            torch.cuda.synchronize()
     else:
         torch.cuda.set_device(0)
     return rank, world, torch.device("cuda", local if world > 1 else 0)
