@@ -22,6 +22,7 @@ thirdparty/mast3r/mast3r/retrieval/processor.py:64-98 for whoever has the files;
 class from tensors (`RetrievalWeights`, a codebook).  SlamSystem accepts any object with
 `update(frame, add_after_query, k, min_thresh)`."""
 import os
+import pickle
 
 import torch
 
@@ -113,6 +114,42 @@ def _whiten(x, mp):
     return out.reshape(x.shape[:-1] + (p.shape[1],)).to(x.dtype)
 
 
+class _ArrayOnlyUnpickler(pickle.Unpickler):
+    """Unpickler for Codebook.state_dict() files (asmk/codebook.py:67-78: nested dicts of python scalars and one
+    float32 ndarray): only the functions numpy's own array pickles name are resolvable, anything else - i.e. every
+    `__reduce__` payload - raises before it is called."""
+
+    def find_class(self, module, name):
+        import numpy as np
+
+        ma = getattr(np, "_core", None) or np.core          # numpy 2.x / 1.x
+        table = {("numpy.core.multiarray", "_reconstruct"): ma.multiarray._reconstruct,
+                 ("numpy._core.multiarray", "_reconstruct"): ma.multiarray._reconstruct,
+                 ("numpy.core.multiarray", "scalar"): ma.multiarray.scalar,
+                 ("numpy._core.multiarray", "scalar"): ma.multiarray.scalar,
+                 ("numpy", "ndarray"): np.ndarray, ("numpy", "dtype"): np.dtype}
+        if (module, name) in table:
+            return table[(module, name)]
+        raise pickle.UnpicklingError(f"codebook file names {module}.{name}: only numpy arrays are loaded")
+
+
+def load_codebook(path):
+    """The (K, d) float32 centroid matrix of an ASMK codebook file without executing anything from it: `.pkl` =
+    Codebook.state_dict() ({'state': {'centroids': ndarray, ...}, ...}) through _ArrayOnlyUnpickler; `.npz` (key
+    'centroids') and `.npy` through numpy.load with allow_pickle=False."""
+    import numpy as np
+
+    if path.endswith(".npy"):
+        return np.ascontiguousarray(np.load(path, allow_pickle=False), dtype=np.float32)
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            return np.ascontiguousarray(z["centroids"], dtype=np.float32)
+    with open(path, "rb") as fh:
+        obj = _ArrayOnlyUnpickler(fh).load()
+    cen = obj["state"]["centroids"] if "state" in obj else obj["centroids"]
+    return np.ascontiguousarray(cen, dtype=np.float32)
+
+
 class RetrievalDatabase:
     """retrieval_database.py:9-166.  `weights`: RetrievalWeights; `centroids`: the ASMK codebook (K, d) f32."""
 
@@ -143,18 +180,24 @@ class RetrievalDatabase:
     def from_checkpoint(cls, modelname, device="cuda"):
         """thirdparty/mast3r/mast3r/retrieval/processor.py:64-98: `<name>.pth` = {'args': Namespace, 'model': state_dict},
         `<name minus its last _field>_codebook.pkl` = Codebook.state_dict() (asmk/codebook.py:67-78).  Files supplied by the
-        user (they are not part of the reference tree); loaded the way the reference loads them."""
-        import pickle
+        user (they are not part of the reference tree).  The reference unpickles both (torch.load weights_only=False,
+        pickle.load); here nothing from either file is executed: the checkpoint goes through torch's weights-only
+        loader with argparse.Namespace (plain attribute container) allow-listed, the codebook through an unpickler that
+        admits the numpy array reconstructors and nothing else (`load_codebook`; `.npy` / `.npz` are accepted too)."""
+        import argparse
 
         assert os.path.isfile(modelname), modelname
-        ckpt = torch.load(modelname, "cpu", weights_only=False)
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            ckpt = torch.load(modelname, "cpu", weights_only=True)
         a = ckpt["args"]
         dname, bname = os.path.split(modelname)
-        cb = os.path.join(dname, "_".join(bname.split("_")[:-1]) + "_codebook.pkl")
-        assert os.path.isfile(cb), cb
-        with open(cb, "rb") as fh:
-            centroids = pickle.load(fh)["state"]["centroids"]
-        w = RetrievalWeights.from_state_dict(ckpt["model"], nfeat=a.nfeat, residual=getattr(a, "residual", False), device=device)
+        stem = os.path.join(dname, "_".join(bname.split("_")[:-1]) + "_codebook")
+        cb = next((stem + ext for ext in (".pkl", ".npz", ".npy") if os.path.isfile(stem + ext)), None)
+        assert cb is not None, stem + ".pkl"
+        centroids = load_codebook(cb)
+        nfeat = a.nfeat if hasattr(a, "nfeat") else a["nfeat"]
+        residual = getattr(a, "residual", False) if not isinstance(a, dict) else a.get("residual", False)
+        w = RetrievalWeights.from_state_dict(ckpt["model"], nfeat=nfeat, residual=residual, device=device)
         return cls(w, torch.from_numpy(centroids), device=device)
 
     @property
@@ -206,8 +249,9 @@ class RetrievalDatabase:
         topk = self.quantize_custom(des, q)
         sig, uniq = self._aggregate(des, topk)
         scores = torch.zeros(self.n_images, dtype=torch.float64, device=des.device)
+        uniq32 = uniq.to(torch.int32)        # a named local: the pointer must outlive the launch's enqueue
         rc = _m.lib().mslam_asmk_search(_m.ptr(self._e_word), _m.ptr(self._e_sig), _m.ptr(self._img_start), self.n_images,
-                                        _m.ptr(uniq.to(torch.int32)), _m.ptr(sig), uniq.numel(), self.sig_words,
+                                        _m.ptr(uniq32), _m.ptr(sig), uniq.numel(), self.sig_words,
                                         float(q["similarity"]["similarity_threshold"]), float(q["similarity"]["alpha"]),
                                         _m.ptr(scores), _m.stream_ptr())
         _m.check(rc, "asmk_search")

@@ -138,12 +138,16 @@ class FrameTracker:
             self._status = torch.zeros(8, dtype=torch.int32, device=dev)
         h, w = (int(img_size[0]), int(img_size[1])) if img_size is not None else (0, 0)
         sa, sb = (cfg["sigma_pixel"], cfg["sigma_depth"]) if use_calib else (cfg["sigma_ray"], cfg["sigma_dist"])
-        self._job = dict(args=(int(use_calib), _m.ptr(T_rel), _m.ptr(Xf.contiguous()), _m.ptr(Xk.contiguous()),
-                               _m.ptr(idx.contiguous()), _m.ptr(Qk.reshape(-1).contiguous()),
-                               _m.ptr(valid.reshape(-1).contiguous()), n, _m.ptr(K.contiguous()) if use_calib else 0,
+        # the contiguous forms are named and kept in the job: _run_rest relaunches with the same pointers after other
+        # allocations have happened on the stream (a temporary .contiguous() copy would be freed at once)
+        Xf_c, Xk_c, idx_c = Xf.contiguous(), Xk.contiguous(), idx.contiguous()
+        Qk_c, valid_c = Qk.reshape(-1).contiguous(), valid.reshape(-1).contiguous()
+        K_c = K.contiguous() if use_calib else None
+        self._job = dict(args=(int(use_calib), _m.ptr(T_rel), _m.ptr(Xf_c), _m.ptr(Xk_c), _m.ptr(idx_c), _m.ptr(Qk_c),
+                               _m.ptr(valid_c), n, _m.ptr(K_c) if use_calib else 0,
                                w, h, float(sa), float(sb), float(cfg["huber"]), int(cfg["pixel_border"]),
                                float(cfg["depth_eps"])),
-                         keep=(T_rel, Xf, Xk, idx, Qk, valid, K), T_rel=T_rel, T_WCk=T_WCk)
+                         keep=(T_rel, Xf_c, Xk_c, idx_c, Qk_c, valid_c, K_c), T_rel=T_rel, T_WCk=T_WCk)
         last = min(self.FIRST_CHUNK, int(cfg["max_iters"])) if chunked else int(cfg["max_iters"])
         return self._enqueue(0, last)
 
