@@ -25,8 +25,14 @@ Graph size: config 3 is a 1 000-frame stream whose keyframe graph grows from 1 t
 times exactly that (no pre-roll).  A short run (the default) first tracks `--preroll` frames untimed (default 500:
 ~63 keyframes, the mean of the schedule) so that the timed steps solve a graph of the mean size.
 
-Multi-GPU (weak scaling): every rank runs its own session (replicas: tracking is sequential in time, no data-path
-collective; the sharded single-session backend is FactorGraph(shard_edges=True), tests/test_shard_gpu.py).
+Multi-GPU.  `python bench.py --gpus N` starts its own N ranks (one process per GPU, before anything touches a GPU) unless
+it already runs under torch.distributed.run.  Two things are measured at N > 1, one after the other:
+  * `value` (weak scaling): every rank runs its own session (replicas: tracking is sequential in time, there is no
+    data-path collective between independent streams);
+  * `sharded_backend` (what BASELINE configs 4 / 5 and the north_star name): ONE session whose backend is sharded over the
+    N ranks (mast3r_slam/shard.py) - rank 0 tracks and drives, keyframe-pair inference + matching are split over the
+    ranks and all-gathered, the global GN accumulates each rank's edges and sums the normal-equation blocks with ONE
+    all-reduce per iteration (RCCL over xGMI), the global TSDF's voxels live on their owner ranks.  `--mode` picks one.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -75,6 +81,9 @@ def parse():
     ap.add_argument("--host-frames", action="store_true",
                     help="PCIe-inclusive variant (DESIGN.md; never the headline value): the RGB frames wait in pinned host "
                          "memory and every run() call first uploads its frames on the tracking stream")
+    ap.add_argument("--mode", choices=("auto", "replicas", "shard-backend"), default="auto",
+                    help="what is timed at N > 1: 'replicas' = N independent sessions (the headline value), 'shard-backend' = one "
+                         "session whose backend is sharded over the N ranks, 'auto' = both, one after the other")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: all ranks on cuda:0 with gloo collectives (rehearses the N>1 code path on a one-GPU box)")
     ap.add_argument("--graphs", action="store_true", help="replay the network as captured HIP graphs (default: eager)")
@@ -148,7 +157,7 @@ def barrier(world):
 class Session:
     """One SLAM session of the product on the procedural room."""
 
-    def __init__(self, args, rank, world, dev, total_frames):
+    def __init__(self, args, rank, world, dev, total_frames, channel=None):
         from mast3r_slam.config import config
         from mast3r_slam.frame import Frame
         from mast3r_slam.mast3r_model import Mast3rConfig, Mast3rHIP, random_state_dict
@@ -180,18 +189,11 @@ class Session:
             wh = lambda: (torch.zeros(1, 1024, dtype=torch.float64), eye + 0.02 * torch.randn(1024, 1024, generator=g, dtype=torch.float64))
             rw = RetrievalWeights(wh(), [(torch.randn(1024, 1024, generator=g) / 32.0, torch.zeros(1024))], wh(), nfeat=300, device=dev)
             retriever = RetrievalDatabase(rw, torch.randn(65536, 1024, generator=g), device=dev)
-        tg = tr = qs = None
-        if not args.no_tsdf:
-            # pre_icp_iters / max_iterations 0: the reference's TSDF pose refinement steps along the UNIT gradient with the
-            # truncation-normalised residual (tsdf_optimizer.py:94-124), an 8x overshoot at trunc_dist 0.12 that throws the
-            # keyframe poses off and sends tracking into relocalisation on this scene (tools/slam_room_probe.py); its
-            # kernels are parity-tested on their own (tests/test_tsdf_gpu.py), the loop runs fusion + re-fusion only
-            tg = dict(config["tsdf_global"], enabled=True, hash_capacity=1 << 22, pre_icp_iters=0, max_iterations=0)
-            tr = dict(config["tsdf_refine"], enabled=True)
-            qs = SynchronousQualityService(device=dev, lookup_both=True)
+        tg, tr = tsdf_cfgs(args)
+        qs = SynchronousQualityService(device=dev, lookup_both=True) if tg is not None else None
         self.system = SlamSystem(self.model, dev, retriever=retriever, frame_group=max(1, args.frame_group),
                                  tsdf_global_cfg=tg, tsdf_refine_cfg=tr, quality_service=qs, decode_ahead=args.decode_ahead,
-                                 backend="inline" if args.no_backend_thread else "thread")
+                                 backend="inline" if args.no_backend_thread else "thread", shard_channel=channel)
         # the stream: RGB frames rendered on the device, resident in HBM before the clock starts
         shp = torch.tensor([[H, W]])
         self.frames = []
@@ -406,15 +408,118 @@ def cpu_baseline(args, graph_kfs, graph_edges, edges_per_kf, kf_every):
                            lc["max_iters"], t_tsdf, kf_every)))
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run, one process per
+    GPU, rendezvous on 127.0.0.1) BEFORE this process has made any GPU call, hand their output through and return their
+    exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def tsdf_cfgs(args):
+    from mast3r_slam.config import config
+
+    if args.no_tsdf:
+        return None, None
+    # pre_icp_iters / max_iterations 0: the reference's TSDF pose refinement steps along the UNIT gradient with the
+    # truncation-normalised residual (tsdf_optimizer.py:94-124), an 8x overshoot at trunc_dist 0.12 that throws the
+    # keyframe poses off and sends tracking into relocalisation on this scene (tools/slam_room_probe.py); its
+    # kernels are parity-tested on their own (tests/test_tsdf_gpu.py), the loop runs fusion + re-fusion only
+    tg = dict(config["tsdf_global"], enabled=True, hash_capacity=1 << 22, pre_icp_iters=0, max_iterations=0)
+    tr = dict(config["tsdf_refine"], enabled=True)
+    return tg, tr
+
+
+def measure_sharded_backend(args, rank, world, dev, ranks_seen):
+    """ONE session, backend sharded over the `world` ranks (mast3r_slam/shard.py).  Rank 0 runs the product loop exactly
+    as in the replica measurement (same frames, same schedule), the other ranks serve.  Returns the report (rank 0)."""
+    from mast3r_slam.shard import OP_PAUSE, OP_STOP, BackendShard, ShardChannel
+
+    ch = ShardChannel(dev)
+    preroll = args.preroll if args.preroll >= 0 else (500 if args.steps < 500 else 0)
+    total = preroll + args.warmup + args.steps
+    phases = [p for p in (preroll, args.warmup) if p] + [args.steps]
+    if rank == 0:
+        ses = Session(args, 0, world, dev, total, channel=ch)
+        marks = []
+        for n in phases:
+            barrier(world)
+            t0 = time.perf_counter()
+            ses.run(n)
+            ses.drain()
+            with ch.lock:
+                ch.announce(OP_PAUSE)
+            barrier(world)
+            marks.append((time.perf_counter() - t0, ses.graph(), dict(ses.system.stats)))
+        with ch.lock:
+            ch.announce(OP_STOP)
+        elapsed = marks[-1][0]
+    else:
+        from mast3r_slam.mast3r_model import Mast3rConfig, Mast3rHIP, random_state_dict
+        from mast3r_slam.synthetic_gpu import RoomGeometryModel
+
+        net = None
+        if not args.no_network:
+            mc = Mast3rConfig(enc_depth=max(1, round(24 * args.depth_scale)), dec_depth=12)
+            sd = random_state_dict(mc, seed=0)
+            net = Mast3rHIP(sd, mc, device=dev, use_graphs=args.graphs)
+            del sd
+        model = RoomGeometryModel(net, dev, H, W, n_frames=1000, seed=0)
+        shard = BackendShard(model, dev, ch, tsdf_global_cfg=tsdf_cfgs(args)[0])
+        elapsed = 0.0
+        for n in phases:
+            barrier(world)
+            t0 = time.perf_counter()
+            assert shard.serve() == "pause"
+            barrier(world)
+            elapsed = time.perf_counter() - t0
+        assert shard.serve() == "stop"
+    import torch.distributed as dist
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    if rank != 0:
+        return None
+    (kf0, e0), st0 = (marks[-2][1], marks[-2][2]) if len(marks) > 1 else ((0, 0), {})
+    (kf1, e1), st1 = marks[-1][1], marks[-1][2]
+    ses.system.shutdown()
+    from mast3r_slam.config import config
+
+    return {"value": args.steps / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "strong",
+            "ranks": world, "ranks_reported_by_collective_library": ranks_seen,
+            "what": "ONE session: rank 0 tracks + drives; keyframe-pair inference + matching split over the ranks "
+                    "(all-gather of the matches), global GN edges split over the ranks with one all-reduce(sum) of the "
+                    "normal-equation blocks per iteration, global TSDF voxels on their owner ranks (replicated point list)",
+            "keyframes": [kf0, kf1], "undirected_edges": [e0, e1],
+            "gn_iterations_per_solve": int(config["local_opt"]["max_iters"]),
+            "allreduce_bytes_per_gn_iteration": (4 * 49 + 2 * 7) * 4 * 2 * e1,
+            "broadcast_bytes_total": ch.bytes_broadcast,
+            "announcements": {str(k): v for k, v in sorted(ch.announced.items())},
+            "relocalised": st1.get("relocalised", 0) - st0.get("relocalised", 0)}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # started without a launcher: be the launcher
+        sys.exit(spawn_ranks(args))
     if os.environ.get("BENCH_WATCHDOG"):   # debug: dump every thread's stack and exit if the run takes longer than this
         import faulthandler
 
         faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG"]), exit=True)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"error: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch one rank per GPU "
+              "(python bench.py --gpus N starts them itself)", file=sys.stderr)
+        sys.exit(2)
     rank, world, dev = dist_setup(args)
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     import mslam_hip
 
     L = mslam_hip.lib()
@@ -426,6 +531,36 @@ def main():
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
         ranks_seen = int(one.item())
+    mode = args.mode
+    if world == 1 and mode == "shard-backend":
+        print("error: --mode shard-backend needs --gpus > 1", file=sys.stderr)
+        sys.exit(2)
+    out = None
+    if mode in ("auto", "replicas"):
+        out = measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen)
+    if world > 1 and mode in ("auto", "shard-backend"):
+        if out is not None:
+            torch.cuda.empty_cache()
+        sb = measure_sharded_backend(args, rank, world, dev, ranks_seen)
+        if rank == 0:
+            if out is None:   # --mode shard-backend: the sharded session is the line's value
+                out = {"metric": "SLAM frames/sec (infer+match+TSDF+GN) @512x384", "value": sb["value"], "unit": "frames/s",
+                       "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sb["ms_per_step"],
+                       "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+                       "data": "synthetic",
+                       "config": {"workload": "ONE synthetic 512x384 session through the product loop, backend sharded over "
+                                              f"{world} ranks (see sharded_backend)", "frame_group": args.frame_group}}
+            out["sharded_backend"] = sb
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
     preroll = args.preroll if args.preroll >= 0 else (500 if args.steps < 500 else 0)
     total = preroll + args.warmup + args.steps
     t_setup = time.perf_counter()
@@ -544,12 +679,11 @@ def main():
             edges_mean = max(1, (e0 + e1) // 2)
             out["cpu_baseline"] = cpu_baseline(args, kfs_mean, edges_mean, max(1.0, new_e / max(1, new_kf)),
                                                args.steps / max(1, new_kf))
-        print(json.dumps(out))
     ses.system.shutdown()
-    if world > 1:
-        import torch.distributed as dist
+    del ses
+    return out if rank == 0 else None
 
-        dist.destroy_process_group()
+
 
 
 if __name__ == "__main__":

@@ -203,6 +203,22 @@ int mslam_tsdf_pose_step(void* table, uint64_t capacity, const float* points, co
                          double lambda, double damping, int update_pose, double* H_out, double* b_out,
                          int* used_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Voxel-sharded volume (north_star: "TSDF voxel blocks shard across the 8 GPUs"; the reference's TSDFVolume is one
+ * python dict, global_volume.py:15-31): a voxel lives in the table of exactly one rank, so a query / pose iteration is
+ * owner-computes: every rank writes what ITS table holds for the seven voxels a query reads (centre, +x, -x, +y, -y,
+ * +z, -z) of every point - out f64[n,7,3] = (state, weight, tsdf), zeros for voxels it does not own - the caller
+ * all-reduces (sum) that array over the ranks, and the *_lookup entry points evaluate global_volume.py:93-128 /
+ * tsdf_optimizer.py:77-124 on it: bit-identical to mslam_tsdf_query / mslam_tsdf_pose_step on one table holding
+ * every voxel.  `pose` != NULL: points are camera-frame, moved with pose first (as mslam_tsdf_pose_step does). */
+int mslam_tsdf_lookup7(void* table, uint64_t capacity, const float* points, int n, const float* pose,
+                       double voxel_size, double* out, void* stream);
+int mslam_tsdf_query_lookup(const double* lookup, int n, double voxel_size, double min_weight, double* value,
+                            double* grad, uint8_t* status, void* stream);
+int mslam_tsdf_pose_step_lookup(const double* lookup, const float* points, const float* conf, int n, float* pose,
+                                int points_in_camera_frame, double voxel_size, double min_weight, double lambda,
+                                double damping, int update_pose, double* H_out, double* b_out, int* used_out,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * MASt3R two-view forward.  Replaces the three model methods the SLAM front/back-end call
  * (mast3r_slam/mast3r_utils.py:34-40,57-64,74): model._encode_image, model._decoder,

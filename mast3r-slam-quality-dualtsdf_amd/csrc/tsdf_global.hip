@@ -388,32 +388,49 @@ __global__ __launch_bounds__(64) void tsdf_replay_big_kernel(void* base, uint64_
 // ---------------------------------------------------------------------------------------------
 // query + gradient (global_volume.py:93-128)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tsdf_query_one(const TsdfTable& t, float px, float py, float pz, float vs,
-                                              double voxel_size, double min_weight, double& value, double* g) {
-  value = 0.0; g[0] = g[1] = g[2] = 0.0;
-  const long long kx = (long long)floorf(px / vs), ky = (long long)floorf(py / vs), kz = (long long)floorf(pz / vs);
-  uint64_t key;
-  if (!pack_key(kx, ky, kz, key)) return 0;
-  const int64_t c = table_find(t, key);
-  if (c < 0 || t.state[c] == 0 || t.weight[c] < min_weight) return 0;
-  value = t.tsdf[c];
-  double denom = 0.0;
-  const long long k[3] = {kx, ky, kz};
+// One voxel as the query sees it: state 0 = absent (not in the table, key out of range, or never fused).
+struct VoxelVal { int state; double w, v; };
+
+__device__ __forceinline__ void voxel_keys7(float px, float py, float pz, float vs, uint64_t (&keys)[7], bool (&ok)[7]) {
+  const long long k[3] = {(long long)floorf(px / vs), (long long)floorf(py / vs), (long long)floorf(pz / vs)};
+  ok[0] = pack_key(k[0], k[1], k[2], keys[0]);
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     long long kp[3] = {k[0], k[1], k[2]}, kn[3] = {k[0], k[1], k[2]};
     kp[a] += 1; kn[a] -= 1;
-    uint64_t keyp, keyn;
-    if (!pack_key(kp[0], kp[1], kp[2], keyp) || !pack_key(kn[0], kn[1], kn[2], keyn)) continue;
-    const int64_t sp = table_find(t, keyp), sn = table_find(t, keyn);
-    if (sp < 0 || sn < 0 || t.state[sp] == 0 || t.state[sn] == 0) continue;
-    if (t.weight[sp] < min_weight || t.weight[sn] < min_weight) continue;
-    if (t.state[sp] == 1 && t.state[sn] == 1) {
+    ok[1 + 2 * a] = pack_key(kp[0], kp[1], kp[2], keys[1 + 2 * a]);
+    ok[2 + 2 * a] = pack_key(kn[0], kn[1], kn[2], keys[2 + 2 * a]);
+  }
+}
+
+__device__ __forceinline__ VoxelVal table_fetch(const TsdfTable& t, uint64_t key, bool ok) {
+  VoxelVal r = {0, 0.0, 0.0};
+  if (!ok) return r;
+  const int64_t c = table_find(t, key);
+  if (c < 0) return r;
+  r.state = t.state[c]; r.w = t.weight[c]; r.v = t.tsdf[c];
+  return r;
+}
+
+// global_volume.py:93-128 on the seven voxels a query reads (centre, +x, -x, +y, -y, +z, -z), however they were fetched
+// (the local table, or - voxel-sharded volumes - the per-voxel sum over the owners' tables).
+__device__ __forceinline__ int tsdf_query_core(const VoxelVal (&vx)[7], double voxel_size, double min_weight,
+                                               double& value, double* g) {
+  value = 0.0; g[0] = g[1] = g[2] = 0.0;
+  if (vx[0].state == 0 || vx[0].w < min_weight) return 0;
+  value = vx[0].v;
+  double denom = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const VoxelVal &sp = vx[1 + 2 * a], &sn = vx[2 + 2 * a];
+    if (sp.state == 0 || sn.state == 0) continue;
+    if (sp.w < min_weight || sn.w < min_weight) continue;
+    if (sp.state == 1 && sn.state == 1) {
       // both values are still np.float32 in the reference: float32 subtract and divide
-      const float d = (float)t.tsdf[sp] - (float)t.tsdf[sn];
+      const float d = (float)sp.v - (float)sn.v;
       g[a] = (double)(d / (float)(2.0 * voxel_size));
     } else {
-      g[a] = (t.tsdf[sp] - t.tsdf[sn]) / (2.0 * voxel_size);
+      g[a] = (sp.v - sn.v) / (2.0 * voxel_size);
     }
     denom += 1.0;
   }
@@ -422,6 +439,62 @@ __device__ __forceinline__ int tsdf_query_one(const TsdfTable& t, float px, floa
   if (nrm < 1.0e-9) { g[0] = g[1] = g[2] = 0.0; return 1; }
   g[0] /= nrm; g[1] /= nrm; g[2] /= nrm;
   return 2;
+}
+
+__device__ __forceinline__ int tsdf_query_one(const TsdfTable& t, float px, float py, float pz, float vs,
+                                              double voxel_size, double min_weight, double& value, double* g) {
+  uint64_t keys[7];
+  bool ok[7];
+  voxel_keys7(px, py, pz, vs, keys, ok);
+  VoxelVal vx[7];
+  vx[0] = table_fetch(t, keys[0], ok[0]);
+  if (vx[0].state == 0 || vx[0].w < min_weight) { value = 0.0; g[0] = g[1] = g[2] = 0.0; return 0; }   // no neighbour probes
+#pragma unroll
+  for (int k = 1; k < 7; k++) vx[k] = table_fetch(t, keys[k], ok[k]);
+  return tsdf_query_core(vx, voxel_size, min_weight, value, g);
+}
+
+// Voxel-sharded volumes (owner-computes query): every rank looks the seven voxels of every point up in ITS
+// table and writes (state, weight, tsdf) - zeros for voxels it does not hold; a voxel lives on exactly one rank, so the
+// all-reduce(sum) of these arrays is, bit for bit, what one table holding everything would return.
+__global__ __launch_bounds__(256) void tsdf_lookup7_kernel(void* base, uint64_t cap, const float* __restrict__ pts,
+                                                           int n, const float* __restrict__ pose, float vs,
+                                                           double* __restrict__ out) {
+  TsdfTable t = table_carve(base, cap);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  if (pose) { const Sim3f T = sim3_load(pose); sim3_act(T, p, p); }
+  uint64_t keys[7];
+  bool ok[7];
+  voxel_keys7(p[0], p[1], p[2], vs, keys, ok);
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const VoxelVal v = table_fetch(t, keys[k], ok[k]);
+    double* o = out + ((size_t)i * 7 + k) * 3;
+    o[0] = (double)v.state; o[1] = v.state ? v.w : 0.0; o[2] = v.state ? v.v : 0.0;
+  }
+}
+
+__device__ __forceinline__ void lookup_load(const double* __restrict__ lk, int i, VoxelVal (&vx)[7]) {
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const double* o = lk + ((size_t)i * 7 + k) * 3;
+    vx[k].state = (int)o[0]; vx[k].w = o[1]; vx[k].v = o[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void tsdf_query_lookup_kernel(const double* __restrict__ lk, int n, double voxel_size,
+                                                                double min_weight, double* __restrict__ value,
+                                                                double* __restrict__ grad, uint8_t* __restrict__ status) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  VoxelVal vx[7];
+  lookup_load(lk, i, vx);
+  double v, g[3];
+  const int st = tsdf_query_core(vx, voxel_size, min_weight, v, g);
+  value[i] = v; grad[3 * i] = g[0]; grad[3 * i + 1] = g[1]; grad[3 * i + 2] = g[2];
+  status[i] = (uint8_t)st;
 }
 
 __global__ __launch_bounds__(256) void tsdf_query_kernel(void* base, uint64_t cap, const float* __restrict__ pts,
@@ -440,10 +513,13 @@ __global__ __launch_bounds__(256) void tsdf_query_kernel(void* base, uint64_t ca
 // TSDF pose normal equations, fp64, deterministic two-stage reduction (tsdf_optimizer.py:94-116).
 // pts are CAMERA-frame points when pose != nullptr (world = pose.act(p), computed in fp32 like
 // lietorch's act), else already world points.  partial: [gridDim.x][36] = 28 (H lower) + 7 (b) + 1 (count)
+// `lookup` != nullptr: the seven voxels of point i come from lookup[i] (all-reduced tsdf_lookup7 output of a voxel-sharded
+// volume) instead of the table.
 __global__ __launch_bounds__(256) void tsdf_pose_accum_kernel(void* base, uint64_t cap, const float* __restrict__ pts,
                                                               const float* __restrict__ conf, int n,
                                                               const float* __restrict__ pose, float vs,
                                                               double voxel_size, double min_weight, float lambda,
+                                                              const double* __restrict__ lookup,
                                                               double* __restrict__ partial) {
   TsdfTable t = table_carve(base, cap);
   double acc[36];
@@ -455,7 +531,15 @@ __global__ __launch_bounds__(256) void tsdf_pose_accum_kernel(void* base, uint64
     float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
     if (pose) sim3_act(T, p, p);
     double v, g[3];
-    if (tsdf_query_one(t, p[0], p[1], p[2], vs, voxel_size, min_weight, v, g) != 2) continue;
+    int st;
+    if (lookup) {
+      VoxelVal vx[7];
+      lookup_load(lookup, i, vx);
+      st = tsdf_query_core(vx, voxel_size, min_weight, v, g);
+    } else {
+      st = tsdf_query_one(t, p[0], p[1], p[2], vs, voxel_size, min_weight, v, g);
+    }
+    if (st != 2) continue;
     if (!isfinite(v)) continue;
     const double P[3] = {p[0], p[1], p[2]};
     double J[7];
@@ -677,25 +761,67 @@ extern "C" int mslam_tsdf_query(void* table, uint64_t capacity, const float* poi
   return MSLAM_OK;
 }
 
-extern "C" int mslam_tsdf_pose_step(void* table, uint64_t capacity, const float* points, const float* conf, int n,
-                                    float* pose, int points_in_camera_frame, double voxel_size, double min_weight,
-                                    double lambda, double damping, int update_pose, double* H_out, double* b_out,
-                                    int* used_out, void* workspace, size_t workspace_bytes, void* stream) {
-  MSLAM_REQUIRE(n >= 0, "tsdf_pose_step: negative count");
-  MSLAM_REQUIRE(table && workspace && (n == 0 || (points && conf)), "tsdf_pose_step: null pointer");
-  MSLAM_REQUIRE(!(update_pose || points_in_camera_frame) || pose, "tsdf_pose_step: pose required");
+static int pose_step_impl(void* table, uint64_t capacity, const double* lookup, const float* points, const float* conf,
+                          int n, float* pose, int points_in_camera_frame, double voxel_size, double min_weight,
+                          double lambda, double damping, int update_pose, double* H_out, double* b_out, int* used_out,
+                          void* workspace, size_t workspace_bytes, void* stream, const char* what) {
+  MSLAM_REQUIRE(n >= 0, "%s: negative count", what);
+  MSLAM_REQUIRE((table || lookup) && workspace && (n == 0 || (points && conf)), "%s: null pointer", what);
+  MSLAM_REQUIRE(!(update_pose || points_in_camera_frame) || pose, "%s: pose required", what);
   int nblk = (n + 255) / 256;
   if (nblk > 64) nblk = 64;
   if (nblk < 1) nblk = 1;
-  MSLAM_REQUIRE(workspace_bytes >= sizeof(double) * 36 * 64, "tsdf_pose_step: workspace needs %zu bytes",
+  MSLAM_REQUIRE(workspace_bytes >= sizeof(double) * 36 * 64, "%s: workspace needs %zu bytes", what,
                 sizeof(double) * 36 * 64);
   double* partial = (double*)workspace;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(tsdf_pose_accum_kernel, dim3(nblk), dim3(256), 0, s, table, capacity, points, conf, n,
                      points_in_camera_frame ? pose : (const float*)nullptr, (float)voxel_size, voxel_size, min_weight,
-                     (float)lambda, partial);
+                     (float)lambda, lookup, partial);
   hipLaunchKernelGGL(tsdf_pose_finish_kernel, dim3(1), dim3(64), 0, s, partial, nblk, damping, H_out, b_out, used_out,
                      pose, update_pose);
-  MSLAM_LAUNCH_CHECK("tsdf_pose_step");
+  return check_hip(hipGetLastError(), what);
+}
+
+extern "C" int mslam_tsdf_pose_step(void* table, uint64_t capacity, const float* points, const float* conf, int n,
+                                    float* pose, int points_in_camera_frame, double voxel_size, double min_weight,
+                                    double lambda, double damping, int update_pose, double* H_out, double* b_out,
+                                    int* used_out, void* workspace, size_t workspace_bytes, void* stream) {
+  MSLAM_REQUIRE(table, "tsdf_pose_step: null table");
+  return pose_step_impl(table, capacity, nullptr, points, conf, n, pose, points_in_camera_frame, voxel_size, min_weight,
+                        lambda, damping, update_pose, H_out, b_out, used_out, workspace, workspace_bytes, stream,
+                        "tsdf_pose_step");
+}
+
+extern "C" int mslam_tsdf_lookup7(void* table, uint64_t capacity, const float* points, int n, const float* pose,
+                                  double voxel_size, double* out, void* stream) {
+  MSLAM_REQUIRE(n >= 0, "tsdf_lookup7: negative count");
+  if (n == 0) return MSLAM_OK;
+  MSLAM_REQUIRE(table && points && out, "tsdf_lookup7: null pointer");
+  hipLaunchKernelGGL(tsdf_lookup7_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, capacity,
+                     points, n, pose, (float)voxel_size, out);
+  MSLAM_LAUNCH_CHECK("tsdf_lookup7");
   return MSLAM_OK;
+}
+
+extern "C" int mslam_tsdf_query_lookup(const double* lookup, int n, double voxel_size, double min_weight, double* value,
+                                       double* grad, uint8_t* status, void* stream) {
+  MSLAM_REQUIRE(n >= 0, "tsdf_query_lookup: negative count");
+  if (n == 0) return MSLAM_OK;
+  MSLAM_REQUIRE(lookup && value && grad && status, "tsdf_query_lookup: null pointer");
+  hipLaunchKernelGGL(tsdf_query_lookup_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, lookup, n,
+                     voxel_size, min_weight, value, grad, status);
+  MSLAM_LAUNCH_CHECK("tsdf_query_lookup");
+  return MSLAM_OK;
+}
+
+extern "C" int mslam_tsdf_pose_step_lookup(const double* lookup, const float* points, const float* conf, int n,
+                                           float* pose, int points_in_camera_frame, double voxel_size,
+                                           double min_weight, double lambda, double damping, int update_pose,
+                                           double* H_out, double* b_out, int* used_out, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  MSLAM_REQUIRE(lookup, "tsdf_pose_step_lookup: null lookup");
+  return pose_step_impl(nullptr, 1024, lookup, points, conf, n, pose, points_in_camera_frame, voxel_size, min_weight,
+                        lambda, damping, update_pose, H_out, b_out, used_out, workspace, workspace_bytes, stream,
+                        "tsdf_pose_step_lookup");
 }

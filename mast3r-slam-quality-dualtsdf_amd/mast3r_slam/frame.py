@@ -117,6 +117,8 @@ class KeyframeStore:
 
     def __init__(self):
         self._kfs = []
+        self._stamps = []      # per keyframe: bumped whenever its pointmap / confidence may have changed
+        self._clock = 0
 
     def __len__(self):
         return len(self._kfs)
@@ -126,14 +128,27 @@ class KeyframeStore:
 
     def __setitem__(self, idx, frame):
         self._kfs[int(idx)] = frame
+        self.touch(idx)
 
     def append(self, frame):
         """Copy-in, as SharedKeyframes does (frame.py:312-314): later updates of the keyframe (pointmap fusion, backend
         poses) do not reach back into the caller's Frame object.  Tensors are shared, not cloned."""
         self._kfs.append(copy.copy(frame))
+        self._stamps.append(0)
+        self.touch(len(self._kfs) - 1)
 
     def pop_last(self):
         self._kfs.pop()
+        self._stamps.pop()
+
+    def touch(self, idx):
+        """Note that keyframe `idx`'s pointmap / confidence changed (assignments do it themselves; code that edits the
+        tensors in place - the local TSDF refiner - calls it).  A sharded backend re-sends touched keyframes."""
+        self._clock += 1
+        self._stamps[int(idx)] = self._clock
+
+    def stamp(self, idx):
+        return self._stamps[int(idx)]
 
     def last_keyframe(self):
         return self._kfs[-1] if self._kfs else None
@@ -280,6 +295,14 @@ class SharedKeyframes:
         self.is_dirty = torch.zeros(buffer, 1, device=device, dtype=torch.bool)
         self.K = torch.zeros(3, 3, device=device, dtype=dtype)
         self.version = torch.zeros(buffer, device=device, dtype=torch.long)
+        self._stamps, self._clock = {}, 0      # host-side change stamps (KeyframeStore.touch / stamp)
+
+    def touch(self, idx):
+        self._clock += 1
+        self._stamps[int(idx)] = self._clock
+
+    def stamp(self, idx):
+        return self._stamps.get(int(idx))
 
     def __getitem__(self, idx) -> Frame:
         with self.lock:
@@ -315,6 +338,7 @@ class SharedKeyframes:
             self.N[idx] = value.N
             self.N_updates[idx] = value.N_updates
             self.is_dirty[idx] = True
+            self.touch(idx)
             return idx
 
     def __len__(self):

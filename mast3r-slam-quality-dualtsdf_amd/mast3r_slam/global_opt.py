@@ -22,7 +22,7 @@ from mast3r_slam.mast3r_utils import mast3r_match_symmetric
 
 
 class FactorGraph:
-    def __init__(self, model, frames, K=None, device="cuda", shard_edges=False):
+    def __init__(self, model, frames, K=None, device="cuda", shard_edges=False, channel=None):
         self.model = model
         self.frames = frames
         self.device = device
@@ -36,6 +36,12 @@ class FactorGraph:
         self.K = K
         self.last_unique_kf_idx = None
         self.shard_edges = shard_edges
+        # driver / shard roles of one session (mast3r_slam/shard.py): the driver announces its sharded calls so that the
+        # shard ranks make them too; None = every rank calls the sharded methods itself (SPMD)
+        self.channel = channel
+        self.group = channel.group if channel is not None else None
+        self._sent_tokens = {}     # keyframe index -> frame_id whose encoder tokens the shards hold
+        self._sent_stamp = {}      # keyframe index -> store stamp of the pointmap the shards hold
 
     # ------------------------------------------------------------------
     def add_factors(self, ii, jj, min_match_frac, is_reloc=False):
@@ -48,11 +54,59 @@ class FactorGraph:
         pos_j = torch.cat([kf.pos for kf in kf_jj])
         shape_i = [kf.img_true_shape for kf in kf_ii]
         shape_j = [kf.img_true_shape for kf in kf_jj]
+        if self._driver:
+            self._announce_add_factors(ii, jj, min_match_frac, is_reloc)
         if self.shard_edges and torch.distributed.is_available() and torch.distributed.is_initialized():
-            res = match_symmetric_sharded(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
+            res = match_symmetric_sharded(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j, group=self.group)
         else:
             res = mast3r_match_symmetric(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
         return self.add_matched_factors(ii, jj, *res, min_match_frac=min_match_frac, is_reloc=is_reloc)
+
+    @property
+    def _driver(self):
+        return self.channel is not None and self.channel.is_driver and self.shard_edges
+
+    def _announce_add_factors(self, ii, jj, min_match_frac, is_reloc):
+        """Driver: the shards make the same add_factors call; tokens of keyframes they have not seen (or that were
+        replaced: a failed relocalisation pops its keyframe) travel first."""
+        from mast3r_slam import shard as sh
+
+        ch = self.channel
+        with ch.lock:
+            new = [int(i) for i in dict.fromkeys(list(ii) + list(jj))
+                   if self._sent_tokens.get(int(i)) != int(self.frames[int(i)].frame_id)]
+            kf0 = self.frames[int(ii[0])]
+            h, w = (int(v) for v in kf0.img_true_shape.reshape(-1)[:2].tolist())
+            ints = [len(ii), int(bool(is_reloc)), h, w, int(kf0.feat.shape[1]), len(new)] + [int(i) for i in ii] + \
+                   [int(j) for j in jj]
+            for i in new:
+                ints += [i, int(self.frames[i].frame_id)]
+            ch.announce(sh.OP_ADD_FACTORS, ints, [float(min_match_frac)])
+            for i in new:
+                kf = self.frames[i]
+                ch.bcast(kf.feat.contiguous())
+                ch.bcast(kf.pos.contiguous())
+                self._sent_tokens[i] = int(kf.frame_id)
+
+    def _announce_solve(self, job):
+        """Driver: pointmaps / confidences of the keyframes that changed since the shards last got them (rows of the
+        job's own copies: exactly what this solve uses), then the solve itself with its start poses."""
+        from mast3r_slam import shard as sh
+
+        ch = self.channel
+        with ch.lock:
+            dirty = job.get("dirty", [])
+            hw = int(job["Xs"].shape[1])
+            for lo in range(0, len(dirty), sh.POINTMAPS_PER_ANNOUNCEMENT):
+                part = dirty[lo:lo + sh.POINTMAPS_PER_ANNOUNCEMENT]
+                rows = torch.tensor([r for r, _ in part], device=job["Xs"].device)
+                pk = torch.cat((job["Xs"][rows], job["Cs"][rows]), dim=2).contiguous()
+                ch.announce(sh.OP_POINTMAPS, [hw, len(part)] + [k for _, k in part])
+                ch.bcast(pk)
+            kid = {"rays": 0, "calib": 1, "points": 2}[job["kind"]]
+            Kf = [float(v) for v in job["K"].reshape(-1).tolist()] if job["K"] is not None else []
+            ch.announce(sh.OP_SOLVE, [kid, int(job["pose_data"].shape[0]), int(job["height"]), int(job["width"])], Kf)
+            ch.bcast(job["pose_data"])
 
     def add_matched_factors(self, ii, jj, idx_i2j, idx_j2i, valid_match_j, valid_match_i, Qii, Qjj, Qji, Qij,
                             min_match_frac, is_reloc=False):
@@ -122,18 +176,30 @@ class FactorGraph:
             Xs = constrain_points_to_ray(img_size, Xs, K)
             height, width = int(img_size[0]), int(img_size[1])
         ii, jj, idx_ii2jj, valid_match, Q = self.prep_two_way_edges()
-        return dict(kind=kind, pin=pin, unique_kf_idx=unique_kf_idx, unique_kf_idx_host=self.last_unique_kf_idx, K=K,
-                    height=height, width=width,
-                    pose_data=T_WCs.data[:, 0, :].contiguous(), Xs=Xs.contiguous(), Cs=Cs.contiguous(),
-                    edges=(ii, jj, idx_ii2jj, valid_match, Q))
+        job = dict(kind=kind, pin=pin, unique_kf_idx=unique_kf_idx, unique_kf_idx_host=self.last_unique_kf_idx, K=K,
+                   height=height, width=width,
+                   pose_data=T_WCs.data[:, 0, :].contiguous(), Xs=Xs.contiguous(), Cs=Cs.contiguous(),
+                   edges=(ii, jj, idx_ii2jj, valid_match, Q))
+        if self._driver:     # which rows the shards do not hold in this state (store stamps; no stamps = all of them)
+            stamp = getattr(self.frames, "stamp", None)
+            dirty = []
+            for r, k in enumerate(self.last_unique_kf_idx.tolist()):
+                st = stamp(k) if stamp is not None else None
+                if st is None or self._sent_stamp.get(k) != st:
+                    dirty.append((r, int(k)))
+                    self._sent_stamp[k] = st
+            job["dirty"] = dirty
+        return job
 
     def run_solve(self, job):
         c, kind, K = self.cfg, job["kind"], job["K"]
         pose_data, Xs, Cs = job["pose_data"], job["Xs"], job["Cs"]
         ii, jj, idx_ii2jj, valid_match, Q = job["edges"]
+        if self._driver:
+            self._announce_solve(job)
         if self.shard_edges and torch.distributed.is_available() and torch.distributed.is_initialized():
             gauss_newton_sharded(kind, pose_data, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, c, job["height"],
-                                 job["width"])
+                                 job["width"], group=self.group)
         elif kind == "rays":
             mast3r_slam_backends.gauss_newton_rays(
                 pose_data, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, c["sigma_ray"], c["sigma_dist"], c["C_conf"],

@@ -84,18 +84,25 @@ class _BackendThread(threading.Thread):
 
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
-                 backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0):
+                 backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0,
+                 shard_channel=None):
+        """`shard_channel` (mast3r_slam/shard.py): this process is the DRIVER rank of a session whose backend is sharded
+        over the ranks of the channel's group - keyframe-pair inference + matching, the global GN (one all-reduce per
+        iteration) and the global TSDF's voxels; the other ranks run BackendShard.serve()."""
         self.model, self.device, self.K = model, torch.device(device), K
         self.keyframes = KeyframeStore() if keyframes is None else keyframes
         self.tracker = FrameTracker(model, self.keyframes, device)
         self.tracker.quality_service = quality_service          # main.py:246
-        self.factor_graph = FactorGraph(model, self.keyframes, K, device, shard_edges=shard_edges)
+        self.shard_channel = shard_channel
+        self.factor_graph = FactorGraph(model, self.keyframes, K, device, shard_edges=shard_edges or shard_channel is not None,
+                                        channel=shard_channel)
         self.retriever = RecentKeyframes(self.keyframes) if retriever is None else retriever
         self.tsdf_manager = None
         if tsdf_global_cfg is not None and tsdf_global_cfg.get("enabled", False):   # main.py:78-88
             from mast3r_slam.tsdf import TSDFGlobalManager
 
-            self.tsdf_manager = TSDFGlobalManager(self.keyframes, tsdf_global_cfg, config.get("use_calib", False), device)
+            self.tsdf_manager = TSDFGlobalManager(self.keyframes, tsdf_global_cfg, config.get("use_calib", False), device,
+                                                  channel=shard_channel)
             self.tsdf_manager.start()
         # the camera-side half of the dual TSDF (main.py:253-287): local block refinement of keyframes that left the
         # sliding window; scheduled and processed by the backend task (synchronous form of the refiner thread)
@@ -214,16 +221,17 @@ class SlamSystem:
     def _apply_commits(self, wait=False):
         """Threaded backend: the global GN runs on copies, outside the hand-over lock; its poses are written into the
         store HERE, by the tracking side on its own stream, once the solve has finished on the device (the reference's
-        backend process writes them whenever it is done, main.py:145-164 - the frontend never waits for a solve)."""
+        backend process writes them whenever it is done, main.py:145-164 - the frontend never waits for a solve).
+        Always called inside a hand-over section (the backend calls it too, in front of the TSDF pose optimiser)."""
         while self._commits:
             job, ev = self._commits[0]
             if not wait and not ev.query():
                 return
-            main = torch.cuda.current_stream(self.device)
-            main.wait_event(ev)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
             for t in job.values():      # allocated on the backend's stream, read here on this one: without the note the
                 if torch.is_tensor(t) and t.is_cuda:   # caching allocator hands the block back to the backend the moment
-                    t.record_stream(main)              # the job is dropped, while this stream's copy is still queued
+                    t.record_stream(cur)               # the job is dropped, while this stream's copy is still queued
             self.factor_graph.commit_solve(job)
             self._commits.pop(0)
 
@@ -390,16 +398,29 @@ class SlamSystem:
             return
         # threaded: the lock (and with it the tracking stream) is held only while keyframe data is copied out; the
         # solve and the fusions run on the copies; the poses are written back by the tracking side (_apply_commits)
+        mgr = self.tsdf_manager
         with self._critical("backend"):
             job = self.factor_graph.prepare_solve(kind)
-            plan = self.tsdf_manager.plan(self.factor_graph) if self.tsdf_manager is not None else None
+            if job is not None:
+                self._chain_pending_poses(job)
+            plan = mgr.plan(self.factor_graph) if mgr is not None else None
         if job is not None:
             self.factor_graph.run_solve(job)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
-            self._commits.append((job, ev))
+            with self._lock:
+                self._commits.append((job, ev))
         if plan is not None:
-            self.tsdf_manager.execute(plan)
+            if job is not None:      # the fusions use the poses THIS solve produced, as the inline order does
+                mgr.retarget(plan, job["unique_kf_idx_host"], job["pose_data"])
+            if not mgr.has_pose_refinement(plan):
+                mgr.execute(plan)            # fusions only: on the copies, outside the lock
+            else:
+                # the TSDF pose optimiser reads and writes keyframe poses in the store: inside the hand-over section,
+                # behind this solve's own write-back (rare configuration: the tracking stream waits for the solve here)
+                with self._critical("backend"):
+                    self._apply_commits(wait=True)
+                    mgr.execute(plan)
         if self.tsdf_refiner is not None:
             torch.cuda.current_stream(self.device).synchronize()   # outside the lock: the refiner reads scalars back
             with self._critical("backend"):
@@ -407,6 +428,22 @@ class SlamSystem:
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         self._backend_done = done
+
+    def _chain_pending_poses(self, job):
+        """A solve whose result is still waiting in `_commits` (the tracking side writes it into the store when it gets
+        there) has not reached the store this job's poses were copied from: take its poses - they were produced on
+        this (the backend's) stream, so stream order makes them visible - for every keyframe both solves hold.  Called
+        under the hand-over lock.  Without it solve N+1 restarts from pre-N poses and later overwrites N's result."""
+        cur = {int(k): r for r, k in enumerate(job["unique_kf_idx_host"].tolist())}
+        for prev, _ in self._commits:
+            pin = prev["pin"]
+            ids = prev["unique_kf_idx_host"].tolist()
+            src = [r for r in range(pin, len(ids)) if int(ids[r]) in cur]
+            if not src:
+                continue
+            dst = [cur[int(ids[r])] for r in src]
+            dev = job["pose_data"].device
+            job["pose_data"][torch.tensor(dst, device=dev)] = prev["pose_data"][torch.tensor(src, device=dev)]
 
     def _refine(self, idx):
         if self.tsdf_refiner is not None:      # main.py:403-421, after the backend task of the keyframe

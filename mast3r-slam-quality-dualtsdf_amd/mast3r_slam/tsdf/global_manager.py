@@ -96,7 +96,10 @@ class TSDFGlobalManager:
     """global_manager.py:177-226 -> same surface (start / shutdown / on_after_backend_solve, .volume / .optimizer /
     .integrator); no threads."""
 
-    def __init__(self, keyframes, cfg, use_calib, device):
+    def __init__(self, keyframes, cfg, use_calib, device, channel=None, shard_id=0, num_shards=1, group=None):
+        """`channel` (mast3r_slam/shard.py, driver rank of a sharded session): this rank keeps shard 0 of the voxels, the
+        shard ranks the others, every volume call is announced.  `shard_id` / `num_shards` / `group` without a channel:
+        every rank runs its own manager on the same keyframes (SPMD)."""
         from .global_volume import TSDFVolume
 
         from .tsdf_optimizer import TSDFPoseOptimizer
@@ -106,7 +109,10 @@ class TSDFGlobalManager:
         self.cfg = cfg
         self.volume = TSDFVolume(voxel_size=cfg.get("voxel_size", 0.03), truncation=cfg.get("trunc_dist", 0.12),
                                  max_weight=cfg.get("max_weight", 100.0), min_weight=cfg.get("min_tsdf_weight", 1.0e-3),
-                                 capacity=int(cfg.get("hash_capacity", 1 << 22)), device=device)
+                                 capacity=int(cfg.get("hash_capacity", 1 << 22)), device=device,
+                                 shard_id=channel.rank if channel is not None else shard_id,
+                                 num_shards=channel.world if channel is not None else num_shards, group=group,
+                                 channel=channel)
         self.optimizer = TSDFPoseOptimizer(self.volume, keyframes, cfg, use_calib, device)
         self.integrator = TSDFGlobalIntegrator(self.volume, keyframes, cfg, self.optimizer)
         self.reintegrate_budget = int(cfg.get("sync_reintegrate_per_solve", 4))
@@ -163,6 +169,29 @@ class TSDFGlobalManager:
                 n = len(self.opt_pending) if self.optimize_budget <= 0 else min(self.optimize_budget, len(self.opt_pending))
                 batch, self.opt_pending = self.opt_pending[:n], self.opt_pending[n:]
         return dict(todo=todo, optimize=batch)
+
+    def retarget(self, plan, kf_idx_host, pose_data):
+        """Threaded owner: plan() ran BEFORE the solve (it copies keyframe data under the hand-over lock), the fusions
+        must happen at the poses the solve produced (the inline order, and the reference: the integrator thread reads
+        T_WC after the backend wrote it, global_manager.py:82-88).  Replaces the pose of every planned fusion whose
+        keyframe the solve held; `kf_idx_host` = the solve's keyframe ids (host), `pose_data` = its (P, 8) poses."""
+        if plan is None:
+            return
+        row = {int(k): r for r, k in enumerate(kf_idx_host.tolist())}
+        todo = []
+        for kind, i, snap in plan["todo"]:
+            if snap is not None and i in row:
+                snap = (snap[0], snap[1], pose_data[row[i]].reshape(1, 8).clone())
+            todo.append((kind, i, snap))
+        plan["todo"] = todo
+
+    def has_pose_refinement(self, plan):
+        """True when execute_optimize(plan) would touch keyframe poses in the store."""
+        if plan is None:
+            return False
+        opt = self.optimizer
+        pre = opt.pre_icp_iters > 0 and any(kind == "new" for kind, _, _ in plan["todo"])
+        return pre or (opt.max_iterations > 0 and len(plan["optimize"]) > 0)
 
     def execute(self, plan):
         if plan is None:

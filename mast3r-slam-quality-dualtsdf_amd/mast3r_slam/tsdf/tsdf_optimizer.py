@@ -55,14 +55,29 @@ class TSDFPoseOptimizer:
 
     def normal_equations(self, points_world, conf):
         """_build_linear_system + _accumulate_system (tsdf_optimizer.py:94-116) for world points:
-        returns (H f64[7,7], b f64[7], used i32) device tensors."""
+        returns (H f64[7,7], b f64[7], used i32) device tensors.  Voxel-sharded volume: collective (owner-computes
+        look-up, one all-reduce), same bits as one table."""
         v = self.volume
         pts = v._dev(points_world, torch.float32).reshape(-1, 3)
         cf = v._dev(conf, torch.float32).reshape(-1)
         H = torch.zeros((7, 7), dtype=torch.float64, device=v.device)
         b = torch.zeros(7, dtype=torch.float64, device=v.device)
         used = torch.zeros(1, dtype=torch.int32, device=v.device)
-        rc = _m.lib().mslam_tsdf_pose_step(
+        L = _m.lib()
+        if v._collective:
+            if v._driver:
+                from mast3r_slam import shard as sh
+
+                with v.channel.lock:
+                    v.channel.announce(sh.OP_TSDF_NEQ, [pts.shape[0]])
+                    v.channel.bcast(torch.cat((pts, cf[:, None]), dim=1).contiguous())
+            lk = v.lookup7(pts)
+            rc = L.mslam_tsdf_pose_step_lookup(
+                _m.ptr(lk), _m.ptr(pts), _m.ptr(cf), pts.shape[0], 0, 0, v.voxel_size, v.min_weight, self.lambda_tsdf,
+                self.damping, 0, _m.ptr(H), _m.ptr(b), _m.ptr(used), _m.ptr(self._ws), self._ws.numel(), _m.stream_ptr())
+            _m.check(rc, "tsdf_pose_step_lookup")
+            return H, b, used
+        rc = L.mslam_tsdf_pose_step(
             _m.ptr(v._table), v.capacity, _m.ptr(pts), _m.ptr(cf), pts.shape[0], 0, 0, v.voxel_size, v.min_weight,
             self.lambda_tsdf, self.damping, 0, _m.ptr(H), _m.ptr(b), _m.ptr(used), _m.ptr(self._ws),
             self._ws.numel(), _m.stream_ptr())
@@ -71,14 +86,34 @@ class TSDFPoseOptimizer:
 
     def refine_pose(self, pose: Sim3, pts_cam, conf, iterations=None):
         """The iteration loop of _optimize_single (tsdf_optimizer.py:76-86) for already-sampled
-        camera-frame points: pose <- exp(delta) * pose, `iterations` times.  Returns the new Sim3."""
+        camera-frame points: pose <- exp(delta) * pose, `iterations` times.  Returns the new Sim3.  Voxel-sharded
+        volume: collective; per iteration every rank looks the moved points up in its shard, one all-reduce (336 KB at
+        2 000 samples), and every rank takes the same step (identical bits, no pose broadcast)."""
         v = self.volume
         iterations = self.max_iterations if iterations is None else iterations
         pts = v._dev(pts_cam, torch.float32).reshape(-1, 3)
         cf = v._dev(conf, torch.float32).reshape(-1)
         data = pose.data.reshape(8).to(device=v.device, dtype=torch.float32).clone()
+        L = _m.lib()
+        if v._collective:
+            n = pts.shape[0]
+            if v._driver:
+                from mast3r_slam import shard as sh
+
+                pk = torch.empty((n + 2, 4), dtype=torch.float32, device=v.device)
+                pk[:n, :3], pk[:n, 3], pk[n], pk[n + 1] = pts, cf, data[:4], data[4:]
+                with v.channel.lock:
+                    v.channel.announce(sh.OP_TSDF_REFINE, [n, int(iterations)])
+                    v.channel.bcast(pk)
+            for _ in range(iterations):
+                lk = v.lookup7(pts, pose=data)
+                rc = L.mslam_tsdf_pose_step_lookup(
+                    _m.ptr(lk), _m.ptr(pts), _m.ptr(cf), n, _m.ptr(data), 1, v.voxel_size, v.min_weight, self.lambda_tsdf,
+                    self.damping, 1, 0, 0, 0, _m.ptr(self._ws), self._ws.numel(), _m.stream_ptr())
+                _m.check(rc, "tsdf_pose_step_lookup")
+            return Sim3(data.reshape(1, 8))
         for _ in range(iterations):
-            rc = _m.lib().mslam_tsdf_pose_step(
+            rc = L.mslam_tsdf_pose_step(
                 _m.ptr(v._table), v.capacity, _m.ptr(pts), _m.ptr(cf), pts.shape[0], _m.ptr(data), 1, v.voxel_size,
                 v.min_weight, self.lambda_tsdf, self.damping, 1, 0, 0, 0, _m.ptr(self._ws), self._ws.numel(),
                 _m.stream_ptr())

@@ -436,6 +436,9 @@ class TSDFRefiner:
         if gw > 0:
             kf.X_canon[mask_hits] = ((1 - gw) * X_canon + gw * X_refined)[mask_hits]
         self._bump_version(block.kf_id, start_version + 1)
+        touch = getattr(self.keyframes, "touch", None)      # the tensors were edited in place: a sharded backend re-sends them
+        if touch is not None:
+            touch(block.kf_id)
         return True, max(hit_ratio, geometric_gain)
 
     # per-keyframe version counter: SharedKeyframes.version (frame.py:251) when the store has one, else a dict

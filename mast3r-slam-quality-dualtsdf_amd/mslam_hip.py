@@ -62,6 +62,9 @@ _SIGNATURES = {
     "mslam_tsdf_header": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp],
     "mslam_tsdf_dump": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp, _c_vp, ctypes.c_uint32, _c_vp],
     "mslam_tsdf_query": [_c_vp, ctypes.c_uint64, _c_vp, _c_int, _c_double, _c_double, _c_vp, _c_vp, _c_vp, _c_vp],
+    "mslam_tsdf_lookup7": [_c_vp, ctypes.c_uint64, _c_vp, _c_int, _c_vp, _c_double, _c_vp, _c_vp],
+    "mslam_tsdf_query_lookup": [_c_vp, _c_int, _c_double, _c_double, _c_vp, _c_vp, _c_vp, _c_vp],
+    "mslam_tsdf_pose_step_lookup": [_c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_int] + [_c_double] * 4 + [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_size, _c_vp],
     "mslam_tsdf_pose_step": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp, _c_int, _c_vp, _c_int] + [_c_double] * 4 + [_c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_size, _c_vp],
 }
 _RESTYPES = {

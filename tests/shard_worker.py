@@ -86,10 +86,79 @@ def main():
         res["edges"] = int(fg.ii.numel())
         res["pose_moved"] = float((poses1[1:, :3] - torch.stack([torch.from_numpy(synthetic.camera_pose(k)[:3].astype(np.float32)) for k in ks[1:]]).to(dev)).abs().max())
         res["world"] = dist.get_world_size()
+    dist.barrier()
+    res.update(driver_and_shards(rank, world, dev, model, H, W))
+    if rank == 0:
         with open(out, "w") as f:
             json.dump(res, f)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def driver_and_shards(rank, world, dev, model, H, W):
+    """The driver / shard roles of mast3r_slam/shard.py: rank 0 runs the PRODUCT loop (SlamSystem, inline backend) with a
+    shard channel - pair inference + matching, the global GN and the global TSDF's voxels (fusion AND the pose
+    optimiser's owner-computes queries) sharded over the ranks - while the other ranks serve; then rank 0 repeats the
+    session alone.  Every pose, the factor graph and the voxel table must be bit-identical."""
+    import numpy as np
+    import torch
+
+    from mast3r_slam.config import config
+    from mast3r_slam.frame import Frame
+    from mast3r_slam.shard import OP_STOP, BackendShard, ShardChannel
+    from mast3r_slam.slam_system import SlamSystem
+    from mast3r_slam.synthetic_gpu import PoseProximityRetriever
+
+    stride, n_frames = 3, 36
+    saved = config["tracking"]["match_frac_thresh"]
+    config["tracking"]["match_frac_thresh"] = 0.72          # a keyframe every ~7 frames at this resolution
+    tcfg = dict(config["tsdf_global"], enabled=True, hash_capacity=1 << 16, pre_icp_iters=0, max_iterations=1,
+                sync_optimize_per_solve=1, sync_reintegrate_per_solve=2, max_points_per_kf=4000, samples_per_kf=500)
+    ch = ShardChannel(dev)
+
+    def session(channel):
+        torch.manual_seed(0)
+        retr = PoseProximityRetriever(lambda fr: stride * int(fr.frame_id), 1000)
+        system = SlamSystem(model, dev, retriever=retr, frame_group=2, tsdf_global_cfg=tcfg, backend="inline",
+                            shard_channel=channel)
+        shp = torch.tensor([[H, W]])
+        img = model.room.rgb(stride * torch.arange(n_frames, device=dev))
+        frames = [Frame(j, img[j:j + 1].clone(), shp, shp, None) for j in range(n_frames)]
+        results = system.run(frames)
+        system.finish()
+        vox = system.tsdf_manager.volume.voxels()
+        H7, b7, used = system.tsdf_manager.optimizer.normal_equations(
+            system.keyframes[1].T_WC.act(system.keyframes[1].X_canon[::97].contiguous()),
+            system.keyframes[1].get_average_conf()[::97, 0].contiguous())
+        fg = system.factor_graph
+        state = dict(poses=torch.stack([r["pose"].reshape(8) for r in results]),
+                     kf=torch.stack([system.keyframes[i].T_WC.data.reshape(8) for i in range(len(system.keyframes))]),
+                     ii=fg.ii, jj=fg.jj, idx=fg.idx_ii2jj, Q=fg.Q_ii2jj, H7=H7, b7=b7, used=used)
+        modes = [int(r["mode"].value) for r in results]
+        return system, state, vox, modes
+
+    out = {}
+    if rank == 0:
+        sys_s, st_s, vox_s, modes_s = session(ch)
+        with ch.lock:
+            ch.announce(OP_STOP)
+        local_voxels = int(sys_s.tsdf_manager.volume._header()[0])
+        sys_1, st_1, vox_1, modes_1 = session(None)
+        out = {"ds_" + k: bool(torch.equal(st_s[k], st_1[k])) for k in st_s}
+        out["ds_modes"] = modes_s == modes_1
+        out["ds_voxel_keys"] = bool(np.array_equal(vox_s[0], vox_1[0]))
+        out["ds_voxel_values"] = bool(np.array_equal(vox_s[1], vox_1[1]) and np.array_equal(vox_s[2], vox_1[2]))
+        out["ds_keyframes"] = len(sys_1.keyframes)
+        out["ds_edges"] = int(sys_1.factor_graph.ii.numel())
+        out["ds_voxels"] = int(len(vox_1[0]))
+        out["ds_voxels_on_rank0"] = local_voxels
+        out["ds_used"] = int(st_1["used"].item())
+        out["ds_announced"] = {str(k): v for k, v in ch.announced.items()}
+    else:
+        shard = BackendShard(model, dev, ch, tsdf_global_cfg=tcfg)
+        assert shard.serve() == "stop"
+    config["tracking"]["match_frac_thresh"] = saved
+    return out
 
 
 if __name__ == "__main__":

@@ -36,11 +36,38 @@ def test_bench_line(device):
     assert "cpu_baseline" not in d                                                              # switched off above
 
 
-def test_bench_two_ranks_on_one_card(device):
-    """The N > 1 path as the driver launches it (torch.distributed.run, one process per rank), rehearsed on one card:
-    --share-gpu puts both ranks on cuda:0 with gloo collectives.  Rank 0 prints the one line; the value is the
-    whole-job aggregate (both sessions' frames over the slowest rank's time); the rank count the collective library
-    reports is in the line; no cpu_baseline at N > 1."""
+def _check_two_rank_line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]     # the libraries' banners went to stderr
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks(device):
+    """`python bench.py --gpus 2` as the driver starts it, WITHOUT a launcher: bench.py spawns one process per rank itself
+    (before touching the GPU); rehearsed on one card (--share-gpu: both ranks on cuda:0, gloo collectives).  Default mode
+    at N > 1 = both measurements: `value` is the whole-job aggregate of two replica sessions (both sessions' frames over
+    the slowest rank's time, weak scaling) and `sharded_backend` is ONE session whose backend (pair inference +
+    matching, GN with one all-reduce per iteration, TSDF voxels) is sharded over the two ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--preroll", "40",
+           "--share-gpu"]
+    d = _check_two_rank_line(subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT))
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 8 / 1e3)) < 1e-6 * d["value"]      # two sessions' frames / max time
+    assert "2 rank(s) reported by the collective library" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d
+    sb = d["sharded_backend"]
+    assert sb["ranks"] == 2 and sb["ranks_reported_by_collective_library"] == 2 and sb["scaling"] == "strong"
+    assert sb["value"] > 0 and abs(sb["value"] * sb["ms_per_step"] / 1e3 - 1.0) < 1e-6       # one session: frames/s = 1/(s per step)
+    assert sb["keyframes"][1] >= 2 and sb["undirected_edges"][1] >= 1 and sb["relocalised"] == 0
+    assert sb["allreduce_bytes_per_gn_iteration"] == 840 * 2 * sb["undirected_edges"][1]
+    assert sb["broadcast_bytes_total"] > 0 and len(sb["announcements"]) >= 4
+
+
+def test_bench_sharded_backend_under_the_launcher(device):
+    """The same under torch.distributed.run (how the driver launches N > 1), sharded-backend measurement only."""
     import socket
 
     with socket.socket() as s:
@@ -49,13 +76,6 @@ def test_bench_two_ranks_on_one_card(device):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4",
-           "--preroll", "40", "--share-gpu"]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]     # the libraries' banners went to stderr
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak"
-    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 8 / 1e3)) < 1e-6 * d["value"]      # two sessions' frames / max time
-    assert "2 rank(s) reported by the collective library" in d["config"]["parallelism"]
-    assert "cpu_baseline" not in d
+           "--preroll", "24", "--share-gpu", "--mode", "shard-backend"]
+    d = _check_two_rank_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT))
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] == d["sharded_backend"]["value"]

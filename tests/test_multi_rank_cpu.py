@@ -126,3 +126,51 @@ def test_two_ranks_gloo():
     kk = np.concatenate([res[0][7], res[1][7]])
     o = np.lexsort((kk[:, 2], kk[:, 1], kk[:, 0]))
     np.testing.assert_array_equal(kk[o], k)
+
+
+def _channel_worker(rank, world, port, q):
+    """ShardChannel (mast3r_slam/shard.py) on gloo / CPU: announcements (op code, integer and float arguments, bit-exact
+    doubles) and tensor broadcasts arrive on the shard rank in the order the driver issued them."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mast3r_slam.shard import OP_ADD_FACTORS, OP_SOLVE, OP_STOP, ShardChannel
+
+        ch = ShardChannel("cpu")
+        got = []
+        if ch.is_driver:
+            ch.announce(OP_ADD_FACTORS, [3, 0, 96, 128, 48, 1, 0, 1, 2, 1, 2, 3, 3, 17], [0.05])
+            ch.bcast(torch.arange(12, dtype=torch.float32).reshape(3, 4))
+            ch.announce(OP_SOLVE, [0, 4, 0, 0], [float(np.pi), -1.0e-300, 3.0])
+            ch.announce(OP_STOP)
+            got = dict(ch.announced)
+        else:
+            op, ints, floats = ch.receive()
+            t = ch.bcast(torch.empty((3, 4), dtype=torch.float32))
+            got.append((op, ints, floats, t.tolist()))
+            got.append(ch.receive())
+            got.append(ch.receive())
+        q.put((rank, got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_channel_roundtrip():
+    from mast3r_slam.shard import OP_ADD_FACTORS, OP_SOLVE, OP_STOP
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_channel_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == {OP_ADD_FACTORS: 1, OP_SOLVE: 1, OP_STOP: 1}
+    a, b, c = res[1]
+    assert a[0] == OP_ADD_FACTORS and a[1] == [3, 0, 96, 128, 48, 1, 0, 1, 2, 1, 2, 3, 3, 17] and a[2] == [0.05]
+    assert a[3] == torch.arange(12, dtype=torch.float32).reshape(3, 4).tolist()
+    assert b == (OP_SOLVE, [0, 4, 0, 0], [float(np.pi), -1.0e-300, 3.0])
+    assert c == (OP_STOP, [], [])

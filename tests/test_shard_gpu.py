@@ -29,3 +29,28 @@ def test_sharded_backend_is_bit_identical_to_one_rank(device, request):
     for k in ("ii", "jj", "idx", "idx2", "vj", "vi", "Q", "Q2", "poses"):
         assert res[k], (k, res)
     assert res["pose_moved"] < 0.05          # and the solve did its job (noisy poses pulled back to the path)
+
+
+def test_driver_and_shard_roles_are_bit_identical_to_one_rank(device, request):
+    """The second half of the workers' run (tests/shard_worker.py::driver_and_shards): rank 0 runs the PRODUCT loop
+    (SlamSystem) as the driver of a sharded session - pair inference + matching, global GN (one all-reduce per
+    iteration), global TSDF voxels incl. the pose optimiser's owner-computes queries - while rank 1 serves
+    (mast3r_slam/shard.py); then rank 0 repeats the session alone.  Poses of every frame and keyframe, the factor graph,
+    the voxel table (keys AND values) and a set of TSDF normal equations must agree bit for bit."""
+    job = getattr(request.config, "_shard_job", None)
+    if job is None:
+        pytest.skip("the two-rank workers were not started (no -m gpu session start hook)")
+    procs, out, logs = job
+    for p in procs:
+        p.wait(timeout=600)
+    tail = "".join(open(lg).read()[-1500:] for lg in logs if os.path.exists(lg))
+    assert all(p.returncode == 0 for p in procs), tail
+    res = json.load(open(out))
+    for k in ("ds_poses", "ds_kf", "ds_ii", "ds_jj", "ds_idx", "ds_Q", "ds_H7", "ds_b7", "ds_used", "ds_modes",
+              "ds_voxel_keys", "ds_voxel_values"):
+        assert res[k] is True, (k, res)
+    assert res["ds_keyframes"] >= 4 and res["ds_edges"] >= res["ds_keyframes"] - 1 and res["ds_used"] > 20
+    # the voxels really were split: the driver's own table holds about half of them
+    assert 0.3 * res["ds_voxels"] < res["ds_voxels_on_rank0"] < 0.7 * res["ds_voxels"], res
+    ann = res["ds_announced"]          # add_factors, pointmaps, solve, fuse, maintain, refine, normal equations, voxels
+    assert len(ann) >= 8 and all(v >= 1 for v in ann.values()), ann

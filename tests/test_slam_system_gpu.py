@@ -167,3 +167,80 @@ def test_relocalisation(device):
     for f, k in zip(frames[6:], ks[6:]):
         err = np.linalg.norm(f.T_WC.data.reshape(-1)[:3].cpu().numpy() - _gauge(T0, synthetic.camera_pose(k)))
         assert err < 0.05, (k, err)
+
+
+def test_threaded_backend_equals_inline_when_drained(device, eager_keyframes):
+    """backend="thread" with the backend drained behind every frame must do exactly what the inline order does: the
+    solve of a keyframe starts from the previous solve's poses and the TSDF fusions (new keyframe + budgeted
+    re-fusions) happen at the poses THAT solve produced, not at the ones copied out in front of it."""
+    from mast3r_slam.config import config
+    from mast3r_slam.slam_system import SlamSystem
+
+    ks = list(range(0, 60, 3))
+    out = {}
+    for backend in ("inline", "thread"):
+        torch.manual_seed(0)
+        tcfg = dict(config["tsdf_global"], enabled=True, pre_icp_iters=0, max_iterations=0, hash_capacity=1 << 18)
+        system = SlamSystem(RoomModel(device), device, frame_group=1, tsdf_global_cfg=tcfg, backend=backend)
+        frames = _frames(ks, device)
+        for i in range(len(frames)):
+            system.run(frames, i, i + 1)
+            system.drain()
+        system.shutdown()
+        torch.cuda.synchronize()
+        out[backend] = (system, frames, system.tsdf_manager.volume.voxels())
+    (si, fi, vi), (st, ft, vt) = out["inline"], out["thread"]
+    assert len(si.keyframes) == len(st.keyframes) >= 3
+    for a, b in zip(fi, ft):
+        assert torch.equal(a.T_WC.data, b.T_WC.data)
+    for i in range(len(si.keyframes)):
+        assert torch.equal(si.keyframes[i].T_WC.data, st.keyframes[i].T_WC.data), i
+    assert np.array_equal(vi[0], vt[0]) and np.array_equal(vi[1], vt[1]) and np.array_equal(vi[2], vt[2])
+
+
+def test_backlogged_solves_start_from_the_previous_result(device, eager_keyframes):
+    """Two keyframe tasks queued back to back while the tracking side has not yet written solve 1's poses into the store:
+    solve 2 must start from solve 1's result (taken from the pending commit), and the store ends up with solve 2's."""
+    from mast3r_slam.slam_system import SlamSystem
+
+    ks = list(range(0, 60, 3))
+    torch.manual_seed(0)
+    system = SlamSystem(RoomModel(device), device, frame_group=1, backend="thread")
+    frames = _frames(ks, device)
+    system.run(frames)
+    system.drain()
+    n_kf = len(system.keyframes)
+    assert n_kf >= 3
+    # knock the keyframe poses off so that a solve has something to do
+    g = torch.Generator(device=device).manual_seed(5)
+    for i in range(1, n_kf):
+        kf = system.keyframes[i]
+        d = kf.T_WC.data.clone()
+        d[..., :3] += 0.02 * torch.randn(3, device=device, generator=g)
+        system.keyframes.update_T_WCs(type(kf.T_WC)(d), torch.tensor([i]))
+    rec = []
+    fg = system.factor_graph
+    run_solve = fg.run_solve
+
+    def recording(job):
+        before = job["pose_data"].clone()
+        run_solve(job)
+        rec.append((job["unique_kf_idx_host"].clone(), before, job["pose_data"].clone()))
+
+    fg.run_solve = recording
+    apply = system._apply_commits
+    system._apply_commits = lambda wait=False: None          # the tracking side is "busy": commits stay pending
+    system._queue_backend(n_kf - 1)
+    system._queue_backend(n_kf - 1)
+    system._worker.drain()
+    system._apply_commits = apply
+    system.drain()
+    torch.cuda.synchronize()
+    assert len(rec) == 2 and torch.equal(rec[0][0], rec[1][0])
+    pin = 1
+    assert (rec[0][1][pin:] - rec[0][2][pin:]).abs().max() > 1e-3          # solve 1 moved the poses ...
+    assert torch.equal(rec[1][1][pin:], rec[0][2][pin:])                     # ... and solve 2 started from them
+    for r, k in enumerate(rec[1][0].tolist()):
+        if r >= pin:
+            assert torch.equal(system.keyframes[int(k)].T_WC.data.reshape(8), rec[1][2][r])
+    system.shutdown()
