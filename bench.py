@@ -459,6 +459,7 @@ def measure_sharded_backend(args, rank, world, dev, ranks_seen):
                 ch.announce(OP_PAUSE)
             barrier(world)
             marks.append((time.perf_counter() - t0, ses.graph(), dict(ses.system.stats)))
+        ses.system.shutdown()             # still announces (the voxel tables report dropped samples): before the stop
         with ch.lock:
             ch.announce(OP_STOP)
         elapsed = marks[-1][0]
@@ -491,7 +492,6 @@ def measure_sharded_backend(args, rank, world, dev, ranks_seen):
         return None
     (kf0, e0), st0 = (marks[-2][1], marks[-2][2]) if len(marks) > 1 else ((0, 0), {})
     (kf1, e1), st1 = marks[-1][1], marks[-1][2]
-    ses.system.shutdown()
     from mast3r_slam.config import config
 
     return {"value": args.steps / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "strong",

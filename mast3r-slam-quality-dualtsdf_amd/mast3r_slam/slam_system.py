@@ -85,7 +85,7 @@ class _BackendThread(threading.Thread):
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
                  backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0,
-                 shard_channel=None):
+                 shard_channel=None, pipeline=True):
         """`shard_channel` (mast3r_slam/shard.py): this process is the DRIVER rank of a session whose backend is sharded
         over the ranks of the channel's group - keyframe-pair inference + matching, the global GN (one all-reduce per
         iteration) and the global TSDF's voxels; the other ranks run BackendShard.serve()."""
@@ -94,6 +94,7 @@ class SlamSystem:
         self.tracker = FrameTracker(model, self.keyframes, device)
         self.tracker.quality_service = quality_service          # main.py:246
         self.shard_channel = shard_channel
+        self.pipeline = bool(pipeline)
         self.factor_graph = FactorGraph(model, self.keyframes, K, device, shard_edges=shard_edges or shard_channel is not None,
                                         channel=shard_channel)
         self.retriever = RecentKeyframes(self.keyframes) if retriever is None else retriever
@@ -137,17 +138,86 @@ class SlamSystem:
         """Track frames[start:stop] (Frame objects, frame.create_frame) in order; returns the per-frame results of
         step().  A sequence may be fed in several calls over the SAME list (the look-ahead state carries over).
         `release` drops the list's reference to a frame once it has been tracked (keyframes live on in the store), so
-        that a long sequence does not keep every pointmap alive."""
+        that a long sequence does not keep every pointmap alive.
+
+        `pipeline` (default): in TRACKING mode frame f+1's matching + pose solve are enqueued BEFORE frame f's verdict is
+        read - on the premise "f is tracked and the keyframe stays" (true for ~88 % of the frames) - so the one host
+        wait per frame no longer leaves the device without work.  When the premise fails (new keyframe, tracking
+        lost, a solve that needed more than its first chunk of iterations) f+1 is rolled back (nothing of it has
+        reached the keyframe store: FrameTracker keeps the fused keyframe in a shadow copy until the verdict is in) and
+        begun again from f's real outcome.  Results are bit-identical to the frame-at-a-time loop."""
         out = []
         stop = len(frames) if stop is None else min(stop, len(frames))
         self._enc_hi = max(self._enc_hi, start)
-        for i in range(start, stop):
-            if self.frame_group > 1:
-                self._look_ahead(frames, i, stop)
-            out.append(self.step(frames[i]))
-            if release:
-                frames[i] = None
+        if not self.pipeline:
+            for i in range(start, stop):
+                if self.frame_group > 1:
+                    self._look_ahead(frames, i, stop)
+                out.append(self.step(frames[i]))
+                if release:
+                    frames[i] = None
+            return out
+        i, pend = start, None                       # pend = (index, handle): begun, verdict not read yet
+        while i < stop or pend is not None:
+            spec = None
+            if i < stop and self.mode == Mode.TRACKING:
+                if self.frame_group > 1:
+                    self._look_ahead(frames, i, stop)
+                spec = (i, self._begin(frames[i]))
+            if pend is not None:
+                k, h = pend
+                with self._critical("main"):
+                    self.tracker.track_resolve(h)
+                    clean = h.kind == "ok" and not h.new_kf and not h.replayed
+                    if spec is not None and not clean:
+                        self.tracker.rollback(spec[1])
+                        self.stats["replayed_frames"] = self.stats.get("replayed_frames", 0) + 1
+                        spec = None
+                    res, add_new_kf = self._end(h)
+                if add_new_kf:
+                    self._queue_backend(len(self.keyframes) - 1)
+                if spec is None:
+                    self.last_T = h.frame.T_WC
+                out.append(res)
+                if release:
+                    frames[k] = None
+            pend = spec
+            if spec is not None:
+                i += 1
+            elif i < stop and self.mode != Mode.TRACKING:      # INIT / RELOC: frame at a time
+                if self.frame_group > 1:
+                    self._look_ahead(frames, i, stop)
+                out.append(self.step(frames[i]))
+                if release:
+                    frames[i] = None
+                i += 1
         return out
+
+    def _begin(self, frame):
+        """First half of step() for a frame in TRACKING mode: everything enqueued, verdict not read."""
+        self._wait_encoded(frame)
+        self._wait_decoded(frame)
+        if self.last_T is not None:
+            frame.T_WC = Sim3(self.last_T.data.clone())
+        with self._critical("main"):
+            self._apply_commits()
+            h = self.tracker.track_begin(frame)
+        self.last_T = frame.T_WC                    # optimistic: the next frame starts from this one's solved pose
+        return h
+
+    def _end(self, h):
+        """Second half (inside the hand-over section): the verdict's consequences -> (step()'s result dict, new_kf)."""
+        frame = h.frame
+        self.stats["frames"] += 1
+        add_new_kf, _, try_reloc = self.tracker.track_finish(h)
+        if try_reloc:
+            self.mode = Mode.RELOC
+        self._note_keyframe_rule(add_new_kf or try_reloc)
+        if add_new_kf:
+            self.keyframes.append(frame)
+            self.stats["keyframes"] += 1
+        return (dict(mode=Mode.TRACKING, new_kf=bool(add_new_kf), try_reloc=bool(try_reloc), pose=frame.T_WC.data.clone()),
+                bool(add_new_kf))
 
     def finish(self):
         """End of the sequence (main.py:449-560): drain the backend, then the local refiner's final pass over the

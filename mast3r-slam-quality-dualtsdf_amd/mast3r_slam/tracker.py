@@ -2,6 +2,8 @@
 values.  Inference + matching + the whole <=50-iteration Sim3 Gauss-Newton run in libmslam_hip.so; the
 quality-service submission (tracker.py:94-145) happens when a `quality_service` is attached (main.py:246), with
 device tensors in the job instead of numpy copies."""
+import copy
+
 import numpy as np
 import torch
 
@@ -12,15 +14,25 @@ from mast3r_slam.geometry import act_Sim3, constrain_points_to_ray, point_to_ray
 from mast3r_slam.mast3r_utils import mast3r_match_asymmetric
 
 
+class _Pending:
+    """One tracked frame between track_begin (everything enqueued, effects applied optimistically) and track_finish."""
+    __slots__ = ("frame", "init_T", "prev_idx", "prev_shadow", "stash", "base", "shadow", "slot", "job", "verdict",
+                 "event", "quality", "T_WCf", "T_CkCf", "Xkf", "Ckf", "Qkf", "Qff", "status", "pack_args", "replayed",
+                 "kind", "vals", "new_kf")
+
+
 class FrameTracker:
+    IN_PLACE_MODES = ("indep_conf",)      # Frame.update_pointmap edits X_canon / C in place in these modes
+
     def __init__(self, model, frames, device):
         self.cfg = config["tracking"]
         self.model = model
         self.keyframes = frames
         self.device = device
         self.reset_idx_f2k()
-        self._ws = None
-        self._status = None
+        self._slots = [dict(ws=None, status=None, host=None), dict(ws=None, status=None, host=None)]
+        self._slot = 0
+        self._shadow = None        # fused state of the current keyframe that has not been written to the store yet
         self.quality_service = None
         self.last_kf_value = None
 
@@ -30,7 +42,22 @@ class FrameTracker:
     # ------------------------------------------------------------------
     def track(self, frame):
         """tracker.py:28-179 -> (new_kf, [Xk, Ck_avg, Xf, Cf_avg, Qkf, Qff], skipped)."""
-        keyframe = self.keyframes.last_keyframe()
+        h = self.track_begin(frame)
+        self.track_resolve(h)
+        return self.track_finish(h)
+
+    # The three phases of track().  A caller that pipelines frames (SlamSystem.run) enqueues frame f+1 (track_begin) BEFORE
+    # it reads frame f's verdict (track_resolve): the one host read per frame then no longer idles the device.
+    # track_begin applies every effect of a tracked frame optimistically ("tracked, keyframe stays", true for ~88 % of
+    # the frames) but keeps the fused keyframe in a private shadow copy; track_finish writes it to the store, or
+    # drops it when the frame was skipped; rollback() undoes a begin whose premise (the previous frame's outcome) failed.
+    def track_begin(self, frame):
+        h = _Pending()
+        h.frame, h.replayed = frame, False
+        h.init_T, h.prev_idx, h.prev_shadow = frame.T_WC, self.idx_f2k, self._shadow
+        h.stash = getattr(frame, "decoded", None)
+        stored = self.keyframes.last_keyframe()
+        keyframe = self._shadow if self._shadow is not None else stored
         idx_f2k, valid_match_k, Xff, Cff, Qff, Xkf, Ckf, Qkf = mast3r_match_asymmetric(
             self.model, frame, keyframe, idx_i2j_init=self.idx_f2k)
         self.idx_f2k = idx_f2k.clone()
@@ -42,7 +69,8 @@ class FrameTracker:
         use_calib = config["use_calib"]
         img_size = frame.img.shape[-2:]
         K = keyframe.K if use_calib else None
-        Xf, Xk, T_WCf, T_WCk, Cf, Ck, meas_k, valid_meas_k = self.get_points_poses(
+        T_WCk = stored.T_WC            # poses live in the store (the backend's write-backs land there)
+        Xf, Xk, T_WCf, _, Cf, Ck, meas_k, valid_meas_k = self.get_points_poses(
             frame, keyframe, idx_f2k, img_size, use_calib, K)
 
         valid_Cf = Cf > self.cfg["C_conf"]
@@ -53,52 +81,122 @@ class FrameTracker:
 
         # ONE host read per tracked frame: the reference branches on the host four times (match fraction :72-75, solver
         # failure :91-93, the two fractions of the keyframe decision :170-177).  Here the solver is enqueued
-        # unconditionally (its result is dropped when the match-fraction gate fails) and the five scalars come back in
-        # one small copy; the unique count is a scatter instead of torch.unique (no second synchronisation).
+        # unconditionally (its result is dropped when the match-fraction gate fails) and the six scalars come back in
+        # one small copy into pinned memory behind an event; the unique count is a scatter instead of torch.unique.
         match_frac = valid_opt.float().mean()
+        h.slot = self._slot
+        self._slot ^= 1
+        self._cur = h
         if not use_calib:
             T_WCf, T_CkCf, status = self._run_async(False, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, None, None, chunked=True)
         else:
             T_WCf, T_CkCf, status = self._run_async(True, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, K, img_size, chunked=True)
+        h.job = getattr(self, "_job", None)
         hits = torch.zeros(valid_kf.numel(), dtype=torch.int32, device=idx_f2k.device)
         hits.index_add_(0, idx_f2k, valid_match_k[:, 0].to(torch.int32))
-        pack = lambda st: torch.stack((match_frac, st[1].float(), st[2].float(), valid_kf.float().mean(),
-                                       (hits > 0).float().mean(), st[0].float())).cpu()
-        verdict = pack(status)
-        if float(verdict[0]) >= self.cfg["min_match_frac"] and int(verdict[5]) == 0 and int(verdict[2]) == 0 \
-                and int(verdict[1]) < int(self.cfg["max_iters"]):
-            T_WCf, T_CkCf, status = self._run_rest()     # rare: the loop needs more than the first chunk
-            verdict = pack(status)
-        self.last_iters = int(verdict[1])
-        if float(verdict[0]) < self.cfg["min_match_frac"]:
-            return False, [], True
-        if int(verdict[2]) != 0:  # "Cholesky failed" (tracker.py:91-93)
-            return False, [], True
-
+        h.pack_args = (match_frac, valid_kf.float().mean(), (hits > 0).float().mean())
+        h.status = status
+        self._post_verdict(h)
+        h.quality = None
         if self.quality_service is not None and not use_calib:   # tracker.py:94-145 (ray-distance residual form)
             Xf_g = Xf[idx_f2k]                                    # the reference's Xf is the gathered one (:181-206)
             rd_k = point_to_ray_dist(Xk, jacobian=False)
-            rd_f = point_to_ray_dist(act_Sim3(T_CkCf, Xf_g, jacobian=False), jacobian=False)
-            vec = T_CkCf.data.view(-1, 8)
+            h.quality = dict(Xf_g=Xf_g, rd_k=rd_k, valid_kf=valid_kf.view(-1), Ck=Ck.view(-1), Qk=Qk.view(-1),
+                             kf_id=int(len(self.keyframes) - 1), frame_id=int(keyframe.frame_id), H=int(img_size[0]),
+                             W=int(img_size[1]))
+        h.base, h.Xkf, h.Ckf, h.Qkf, h.Qff = keyframe, Xkf, Ckf, Qkf, Qff
+        self._apply(h, T_WCf, T_CkCf)
+        return h
+
+    def _post_verdict(self, h):
+        """The six scalars of the verdict -> pinned host memory, asynchronously, with an event behind the copy."""
+        st = h.status
+        mf, kf_frac, uniq = h.pack_args
+        dev = torch.stack((mf, st[1].float(), st[2].float(), kf_frac, uniq, st[0].float()))
+        sl = self._slots[h.slot]
+        if sl["host"] is None:
+            sl["host"] = torch.empty(6, dtype=torch.float32).pin_memory()
+        sl["host"].copy_(dev, non_blocking=True)
+        h.event = torch.cuda.Event()
+        h.event.record()
+        h.verdict = sl["host"]
+
+    def _apply(self, h, T_WCf, T_CkCf):
+        """Optimistic effects of a tracked frame (tracker.py:147-168): the frame's pose, the keyframe's pointmap fused
+        with the frame's view of it - into a shadow copy, the store is written by track_finish."""
+        h.T_WCf, h.T_CkCf = T_WCf, T_CkCf
+        h.frame.T_WC = T_WCf
+        Xkk = T_CkCf.act(h.Xkf)
+        shadow = copy.copy(h.base)
+        if config["tracking"]["filtering_mode"] in self.IN_PLACE_MODES:
+            shadow.X_canon, shadow.C = shadow.X_canon.clone(), shadow.C.clone()
+        shadow.update_pointmap(Xkk, h.Ckf)
+        h.shadow = shadow
+        self._shadow = shadow
+
+    def track_resolve(self, h):
+        """Reads the verdict (the one host wait of a tracked frame) -> "ok" or "skip".  When the solver needed more than
+        the first chunk of iterations (rare) the rest runs now and the optimistic effects are redone from its result;
+        `h.replayed` then tells a pipelining caller that a frame begun on top of this one saw stale inputs."""
+        h.event.synchronize()
+        v = h.verdict.tolist()
+        if v[0] >= self.cfg["min_match_frac"] and int(v[5]) == 0 and int(v[2]) == 0 and int(v[1]) < int(self.cfg["max_iters"]):
+            self._cur = h
+            T_WCf, T_CkCf, h.status = self._run_rest()     # rare: the loop needs more than the first chunk
+            self._post_verdict(h)
+            h.event.synchronize()
+            v = h.verdict.tolist()
+            later = self._shadow if self._shadow is not h.shadow else None
+            self._apply(h, T_WCf, T_CkCf)
+            if later is not None:          # a frame was begun on top of the stale shadow: its caller rolls it back
+                self._shadow = later
+            h.replayed = True
+        h.vals = v
+        self.last_iters = int(v[1])
+        skip = v[0] < self.cfg["min_match_frac"] or int(v[2]) != 0     # tracker.py:72-75 / "Cholesky failed" :91-93
+        h.kind = "skip" if skip else "ok"
+        h.new_kf = (not skip) and min(float(v[3]), float(v[4])) < self.cfg["match_frac_thresh"]     # tracker.py:170-177
+        return h.kind
+
+    def track_finish(self, h):
+        """Host-side consequences of the verdict -> track()'s return value."""
+        frame = h.frame
+        if h.kind == "skip":
+            frame.T_WC = h.init_T
+            if self._shadow is h.shadow:
+                self._shadow = h.prev_shadow
+            return False, [], True
+        if h.quality is not None:
+            q = h.quality
+            rd_f = point_to_ray_dist(act_Sim3(h.T_CkCf, q["Xf_g"], jacobian=False), jacobian=False)
+            vec = h.T_CkCf.data.view(-1, 8)
             w = vec[..., 6].clamp(-1.0, 1.0).abs()
             self.quality_service.submit({
-                "kf_id": int(len(self.keyframes) - 1), "frame_id": int(keyframe.frame_id), "H": int(img_size[0]),
-                "W": int(img_size[1]), "valid_kf": valid_kf.view(-1), "r_pix": torch.linalg.norm(rd_k - rd_f, dim=1),
-                "Ck": Ck.view(-1), "Qk": Qk.view(-1), "t_norm": vec[..., :3].norm(dim=-1).mean(),
-                "theta": (2.0 * torch.arccos(w)).mean()})
-
-        frame.T_WC = T_WCf
-        Xkk = T_CkCf.act(Xkf)
-        keyframe.update_pointmap(Xkk, Ckf)
+                "kf_id": q["kf_id"], "frame_id": q["frame_id"], "H": q["H"], "W": q["W"], "valid_kf": q["valid_kf"],
+                "r_pix": torch.linalg.norm(q["rd_k"] - rd_f, dim=1), "Ck": q["Ck"], "Qk": q["Qk"],
+                "t_norm": vec[..., :3].norm(dim=-1).mean(), "theta": (2.0 * torch.arccos(w)).mean()})
+        keyframe = h.shadow
+        keyframe.T_WC = self.keyframes.last_keyframe().T_WC      # never write a pose back that a solve has replaced since
         self.keyframes[len(self.keyframes) - 1] = keyframe
-
-        match_frac_k, unique_frac_f = float(verdict[3]), float(verdict[4])
+        if self._shadow is h.shadow:
+            self._shadow = None                                   # the store holds it now
+        match_frac_k, unique_frac_f = float(h.vals[3]), float(h.vals[4])
         self.last_kf_value = min(match_frac_k, unique_frac_f)     # how far the keyframe rule is from firing
-        new_kf = min(match_frac_k, unique_frac_f) < self.cfg["match_frac_thresh"]
+        new_kf = h.new_kf
         if new_kf:
             self.reset_idx_f2k()
+            self._shadow = None
         return (new_kf, [keyframe.X_canon, keyframe.get_average_conf(), frame.X_canon, frame.get_average_conf(),
-                         Qkf, Qff], False)
+                         h.Qkf, h.Qff], False)
+
+    def rollback(self, h):
+        """Undo track_begin(h) (nothing of it has reached the store): the tracker's chain state, the frame's own fields
+        and the group-decode result it consumed, so that the frame can be begun again."""
+        self.idx_f2k, self._shadow = h.prev_idx, h.prev_shadow
+        f = h.frame
+        f.T_WC, f.X_canon, f.C, f.N, f.N_updates = h.init_T, None, None, 0, 0
+        if h.stash is not None:
+            f.decoded = h.stash
 
     def get_points_poses(self, frame, keyframe, idx_f2k, img_size, use_calib, K=None):
         """tracker.py:181-206.  Unlike the reference this returns the UN-gathered frame points and
@@ -125,7 +223,9 @@ class FrameTracker:
         """Enqueues the GN loop; returns (T_WCf, T_CkCf, status) with `status` a device i32[8]
         ([done, iterations, failed, ...]) that the caller reads when it needs the verdict.  chunked=True enqueues only
         the first FIRST_CHUNK iterations (a tracked frame needs ~5; 50 launch pairs that exit at once would cost more
-        host time than the solve): the caller checks `done` and calls _run_rest when the loop is still running."""
+        host time than the solve): the caller checks `done` and calls _run_rest when the loop is still running.
+        Loop state (workspace, status) is double-buffered: the frame begun last and the one begun before it (whose
+        verdict may still ask for the rest of its iterations) never share it."""
         cfg = self.cfg
         dev = Xf.device
         idx = self._idx if idx is None else idx
@@ -133,9 +233,11 @@ class FrameTracker:
         T_rel = (T_WCk.inv() * T_WCf).data.reshape(8).contiguous().clone()
         L = _m.lib()
         need = L.mslam_track_workspace_bytes(n)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            self._status = torch.zeros(8, dtype=torch.int32, device=dev)
+        cur = getattr(self, "_cur", None)
+        sl = self._slots[cur.slot if cur is not None else 0]
+        if sl["ws"] is None or sl["ws"].numel() < need:
+            sl["ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+            sl["status"] = torch.zeros(8, dtype=torch.int32, device=dev)
         h, w = (int(img_size[0]), int(img_size[1])) if img_size is not None else (0, 0)
         sa, sb = (cfg["sigma_pixel"], cfg["sigma_depth"]) if use_calib else (cfg["sigma_ray"], cfg["sigma_dist"])
         # the contiguous forms are named and kept in the job: _run_rest relaunches with the same pointers after other
@@ -147,22 +249,23 @@ class FrameTracker:
                                _m.ptr(valid_c), n, _m.ptr(K_c) if use_calib else 0,
                                w, h, float(sa), float(sb), float(cfg["huber"]), int(cfg["pixel_border"]),
                                float(cfg["depth_eps"])),
-                         keep=(T_rel, Xf_c, Xk_c, idx_c, Qk_c, valid_c, K_c), T_rel=T_rel, T_WCk=T_WCk)
+                         keep=(T_rel, Xf_c, Xk_c, idx_c, Qk_c, valid_c, K_c), T_rel=T_rel, T_WCk=T_WCk, slot=sl)
         last = min(self.FIRST_CHUNK, int(cfg["max_iters"])) if chunked else int(cfg["max_iters"])
-        return self._enqueue(0, last)
+        return self._enqueue(self._job, 0, last)
 
-    def _enqueue(self, first, last):
-        cfg, job = self.cfg, self._job
+    def _enqueue(self, job, first, last):
+        cfg, sl = self.cfg, job["slot"]
         rc = _m.lib().mslam_track_pose(*job["args"], int(first), int(last), float(cfg["rel_error"]),
-                                       float(cfg["delta_norm"]), _m.ptr(self._status), _m.ptr(self._ws),
-                                       self._ws.numel(), _m.stream_ptr())
+                                       float(cfg["delta_norm"]), _m.ptr(sl["status"]), _m.ptr(sl["ws"]),
+                                       sl["ws"].numel(), _m.stream_ptr())
         _m.check(rc, "track_pose")
         T_CkCf = Sim3(job["T_rel"].reshape(1, 8))
-        return job["T_WCk"] * T_CkCf, T_CkCf, self._status
+        return job["T_WCk"] * T_CkCf, T_CkCf, sl["status"]
 
     def _run_rest(self):
         """The iterations behind the first chunk (same loop state, same results as one uninterrupted loop)."""
-        return self._enqueue(min(self.FIRST_CHUNK, int(self.cfg["max_iters"])), int(self.cfg["max_iters"]))
+        job = self._cur.job if getattr(self, "_cur", None) is not None and self._cur.job is not None else self._job
+        return self._enqueue(job, min(self.FIRST_CHUNK, int(self.cfg["max_iters"])), int(self.cfg["max_iters"]))
 
     def opt_pose_ray_dist_sim3(self, Xf, Xk, T_WCf, T_WCk, Qk, valid, idx=None):
         """tracker.py:225-266 -> (T_WCf, T_CkCf, ok)."""

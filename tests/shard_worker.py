@@ -152,7 +152,7 @@ def driver_and_shards(rank, world, dev, model, H, W):
         out["ds_edges"] = int(sys_1.factor_graph.ii.numel())
         out["ds_voxels"] = int(len(vox_1[0]))
         out["ds_voxels_on_rank0"] = local_voxels
-        out["ds_used"] = int(st_1["used"].item())
+        out["ds_points_used"] = int(st_1["used"].item())
         out["ds_announced"] = {str(k): v for k, v in ch.announced.items()}
     else:
         shard = BackendShard(model, dev, ch, tsdf_global_cfg=tcfg)

@@ -49,7 +49,7 @@ def test_driver_and_shard_roles_are_bit_identical_to_one_rank(device, request):
     for k in ("ds_poses", "ds_kf", "ds_ii", "ds_jj", "ds_idx", "ds_Q", "ds_H7", "ds_b7", "ds_used", "ds_modes",
               "ds_voxel_keys", "ds_voxel_values"):
         assert res[k] is True, (k, res)
-    assert res["ds_keyframes"] >= 4 and res["ds_edges"] >= res["ds_keyframes"] - 1 and res["ds_used"] > 20
+    assert res["ds_keyframes"] >= 4 and res["ds_edges"] >= res["ds_keyframes"] - 1 and res["ds_points_used"] > 20
     # the voxels really were split: the driver's own table holds about half of them
     assert 0.3 * res["ds_voxels"] < res["ds_voxels_on_rank0"] < 0.7 * res["ds_voxels"], res
     ann = res["ds_announced"]          # add_factors, pointmaps, solve, fuse, maintain, refine, normal equations, voxels
