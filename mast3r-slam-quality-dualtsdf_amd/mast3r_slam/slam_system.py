@@ -254,6 +254,7 @@ class SlamSystem:
                     self.mode = Mode.RELOC
                 self._note_keyframe_rule(add_new_kf or try_reloc)
             elif mode == Mode.RELOC:                    # main.py:375-385
+                self.tracker._shadow = None             # whatever comes next is tracked against the store's keyframe
                 X, C = mu.mast3r_inference_mono(self.model, frame)
                 frame.update_pointmap(X, C)
                 if self._relocalization(frame):

@@ -128,6 +128,7 @@ class FrameTracker:
         h.frame.T_WC = T_WCf
         Xkk = T_CkCf.act(h.Xkf)
         shadow = copy.copy(h.base)
+        shadow._in_store, shadow._replaced_by = False, None      # (the copy inherits the marks of a committed base)
         if config["tracking"]["filtering_mode"] in self.IN_PLACE_MODES:
             shadow.X_canon, shadow.C = shadow.X_canon.clone(), shadow.C.clone()
         shadow.update_pointmap(Xkk, h.Ckf)
@@ -146,8 +147,10 @@ class FrameTracker:
             self._post_verdict(h)
             h.event.synchronize()
             v = h.verdict.tolist()
-            later = self._shadow if self._shadow is not h.shadow else None
+            stale = h.shadow
+            later = self._shadow if self._shadow is not stale else None
             self._apply(h, T_WCf, T_CkCf)
+            stale._replaced_by = h.shadow  # an undo that restores the stale shadow gets the redone one (_live)
             if later is not None:          # a frame was begun on top of the stale shadow: its caller rolls it back
                 self._shadow = later
             h.replayed = True
@@ -164,7 +167,7 @@ class FrameTracker:
         if h.kind == "skip":
             frame.T_WC = h.init_T
             if self._shadow is h.shadow:
-                self._shadow = h.prev_shadow
+                self._shadow = self._live(h.prev_shadow)
             return False, [], True
         if h.quality is not None:
             q = h.quality
@@ -178,6 +181,7 @@ class FrameTracker:
         keyframe = h.shadow
         keyframe.T_WC = self.keyframes.last_keyframe().T_WC      # never write a pose back that a solve has replaced since
         self.keyframes[len(self.keyframes) - 1] = keyframe
+        keyframe._in_store = True                                 # a later frame's undo must not resurrect it as a shadow
         if self._shadow is h.shadow:
             self._shadow = None                                   # the store holds it now
         match_frac_k, unique_frac_f = float(h.vals[3]), float(h.vals[4])
@@ -189,10 +193,17 @@ class FrameTracker:
         return (new_kf, [keyframe.X_canon, keyframe.get_average_conf(), frame.X_canon, frame.get_average_conf(),
                          h.Qkf, h.Qff], False)
 
+    @staticmethod
+    def _live(shadow):
+        """A shadow that has been written to the store since is no shadow any more (the store's keyframe is read)."""
+        while shadow is not None and getattr(shadow, "_replaced_by", None) is not None:
+            shadow = shadow._replaced_by
+        return None if shadow is None or getattr(shadow, "_in_store", False) else shadow
+
     def rollback(self, h):
         """Undo track_begin(h) (nothing of it has reached the store): the tracker's chain state, the frame's own fields
         and the group-decode result it consumed, so that the frame can be begun again."""
-        self.idx_f2k, self._shadow = h.prev_idx, h.prev_shadow
+        self.idx_f2k, self._shadow = h.prev_idx, self._live(h.prev_shadow)
         f = h.frame
         f.T_WC, f.X_canon, f.C, f.N, f.N_updates = h.init_T, None, None, 0, 0
         if h.stash is not None:
