@@ -14,6 +14,8 @@ int launch_gemm_t128x64(const GemmArgs& a, int stages, hipStream_t s);
 int launch_gemm_t256(const GemmArgs& a, int bn, hipStream_t s);
 int launch_gemm_t192(const GemmArgs& a, hipStream_t s);
 int launch_gemm_t256w8(const GemmArgs& a, hipStream_t s);
+int launch_gemm_8p(const GemmArgs& a, hipStream_t s);      // gemm8p.hip: 256x256, phase-interleaved K loop
+bool gemm8p_supports(const GemmArgs& a);
 
 // Per-shape tile choices for plain (non-conv, ungrouped) problems: the measured table below, editable at run time
 // through mslam_gemm_tile_override (tools/insitu_tune.py finds the entries by timing whole network stages).
@@ -116,6 +118,7 @@ static int launch_gemm_impl(const GemmArgs& a, hipStream_t stream) {
   // traffic and win as soon as they still cover the chip.
   // MSLAM_GEMM="<cfg>" forces one configuration for experiments:
   //   642/643/644: 64x64 ring 2/3/4; 1262/1263: 128x64 ring 2/3; 1242: 128x128 4 waves; 1282/1283: 128x128 8 waves ring 2/3;
+  //   8256: 256x256 8 waves, phase-interleaved K loop (gemm8p.hip; plain epilogue only, else 2256);
   //   2128: 256x128 8 waves; 2256: 256x256 16 waves; 2192: 192x256 8 waves; 2258: 256x256 8 waves (A/B only: slower than
   //   2256 and 2192 on every shape of the table, profiles/r02_gemm_cfg_ab.log)
   static int forced = -2;
@@ -158,6 +161,7 @@ static int launch_gemm_impl(const GemmArgs& a, hipStream_t stream) {
     case 2256: return launch_gemm_t256(a, 256, stream);
     case 2192: return launch_gemm_t192(a, stream);
     case 2258: return launch_gemm_t256w8(a, stream);
+    case 8256: return gemm8p_supports(a) ? launch_gemm_8p(a, stream) : launch_gemm_t256(a, 256, stream);
     default: MSLAM_REQUIRE(false, "gemm: unknown configuration %d", cfg);
   }
 }

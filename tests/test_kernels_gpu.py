@@ -40,7 +40,7 @@ def test_gemm_bf16(device, M, N, K, act, out_bf16):
     assert _rel(out.float(), ref) <= (5e-3 if out_bf16 else 2e-3), _rel(out.float(), ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(3072, 3072, 1024), (3072, 768, 3072), (1000, 200, 520)])
+@pytest.mark.parametrize("M,N,K", [(3072, 3072, 1024), (3072, 768, 3072), (1000, 200, 520), (3072, 4096, 1024)])
 def test_gemm_result_does_not_depend_on_the_tile(device, M, N, K):
     """Every tile configuration accumulates an output element over K in the same order, so the choice (heuristic,
     measured table, mslam_gemm_tile_override) never changes a bit of the result - what makes batched network calls
@@ -52,7 +52,7 @@ def test_gemm_result_does_not_depend_on_the_tile(device, M, N, K):
     bias = (torch.rand(N, generator=g) - 0.5).to(device)
     outs = []
     try:
-        for cfg in (0, 642, 643, 644, 1262, 1263, 1242, 1282, 1283, 2128, 2256):
+        for cfg in (0, 642, 643, 644, 1262, 1263, 1242, 1282, 1283, 2128, 2256, 2192, 8256):   # 8256: gemm8p.hip
             m.check(m.lib().mslam_gemm_tile_override(M, N, K, cfg), "override")
             out = torch.empty((M, N), dtype=torch.float32, device=device)
             m.check(m.lib().mslam_gemm_bf16(m.ptr(A), m.ptr(Wt), m.ptr(bias), 0, m.ptr(out), M, N, K, 1, 0, m.stream_ptr()), "gemm")
