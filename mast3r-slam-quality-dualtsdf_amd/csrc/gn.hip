@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256) void gn_compact_kernel(
     const float* __restrict__ Xs, const float* __restrict__ Cs, const int* __restrict__ ii_edge,
     const int* __restrict__ jj_edge, const int64_t* __restrict__ idx_ii2jj,
     const uint8_t* __restrict__ valid_match, const float* __restrict__ Q, int num_points, int chunk_len,
-    float C_thresh, float Q_thresh, float* __restrict__ stream, int* __restrict__ counts) {
-  const int e = blockIdx.y, chunk = blockIdx.x, S = gridDim.x;
+    float C_thresh, float Q_thresh, float* __restrict__ stream, int* __restrict__ counts, int S) {
+  // one-dimensional grid of S x edges workgroups (a y dimension would cap the edge count at 65 535)
+  const int e = blockIdx.x / S, chunk = blockIdx.x - e * S;
   const int ix = ii_edge[e], jx = jj_edge[e];
   const float* __restrict__ Xi_base = Xs + (size_t)ix * num_points * 3;
   const float* __restrict__ Xj_base = Xs + (size_t)jx * num_points * 3;
@@ -308,9 +309,9 @@ __global__ __launch_bounds__(256) void gn_accum_kernel(const GnState* __restrict
                                                        const float* __restrict__ econst,
                                                        const float* __restrict__ stream,
                                                        const int* __restrict__ counts, int chunk_len,
-                                                       GnParams P, float* __restrict__ partial) {
+                                                       GnParams P, float* __restrict__ partial, int S) {
   if (st->done) return;
-  const int e = blockIdx.y, chunk = blockIdx.x, S = gridDim.x;
+  const int e = blockIdx.x / S, chunk = blockIdx.x - e * S;     // one-dimensional grid: no 65 535-edge cap
   // wave-uniform per-edge constants -> scalar loads
   const float* cc = econst + (size_t)e * kEdgeConst;
   const EdgeConst c = {cc[0], cc[1], cc[2], cc[3], cc[4], cc[5], cc[6], cc[7], cc[8], cc[9], cc[10], cc[11]};
@@ -528,7 +529,9 @@ __global__ __launch_bounds__(64) void gn_assemble_kernel(const GnState* __restri
 // diagonal block D = A11 - Lp Lp^T itself (same code in every workgroup: identical bits), factors it
 // in LDS and solves its own rows X L11^T = A21'.  Nobody writes A11 in this launch (the other
 // workgroups read it): the factor of the diagonal block goes to the side array Ldiag[panel].
-// j0 = -NB is the prologue: no update, only the first panel is finished.
+// update == 0: no trailing update, only the panel at j1 = j0 + NB is finished (the prologue, j0 = -NB, and the first
+// panel of every outer block of the two-level schedule below).  clim: columns >= clim are left alone (they receive
+// this panel's update later, as part of their outer block's rank-W update, chol_outer_kernel).
 // Envelope: with the keyframes in temporal order H is a band (consecutive + recent-neighbour edges) plus a few far
 // rows (loop closures), and LL^T fill stays inside each row's envelope [first non-zero column, diagonal].  tmin32[b] =
 // the smallest first column over the rows [32 b, 32 b + 32) (written by gn_assemble).  A tile whose row block or
@@ -541,7 +544,7 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 template <int NB>
 __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st, double* __restrict__ A,
                                                         double* __restrict__ Ldiag, int np, int ld, int j0,
-                                                        const int* __restrict__ tmin32) {
+                                                        const int* __restrict__ tmin32, int update, int clim) {
   if (st->done) return;
   constexpr int LS = NB + 2;   // LDS row stride of the panel rows: conflict-free f64 MFMA operand reads
   constexpr int TS = kTile + 1;
@@ -550,8 +553,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
   if (tj > ti) return;
   const int j1 = j0 + NB;
   const int r0 = j1 + ti * kTile, c0 = j1 + tj * kTile;
-  if (r0 > np || c0 >= np) return;
-  const bool has_update = j0 >= 0;
+  if (r0 > np || c0 >= np || c0 >= clim) return;
+  const bool has_update = update != 0;
   {
     const int last = np >> 5;                  // r0, c0 are multiples of 32; a tile covers two 32-row blocks
     const int fr = min(tmin32[min(r0 >> 5, last)], tmin32[min((r0 >> 5) + 1, last)]);
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
       for (int g = 0; g < 4; g++) {
         const int r = r0 + 32 * wr + 16 * m + frow + 4 * g;
         const int c = c0 + 32 * wc + 16 * n + fcol;
-        const bool in = r <= np && c < np && c <= r;
+        const bool in = r <= np && c < np && c <= r && c < clim;
         const double v = A[in ? (size_t)r * ld + c : (size_t)0];  // always-valid address + select: no branch
         acc[m][n][g] = in ? v : 0.0;
       }
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
           for (int g = 0; g < 4; g++) {
             const int r = r0 + 32 * wr + 16 * m + frow + 4 * g;
             const int c = c0 + 32 * wc + 16 * n + fcol;
-            if (r <= np && c < np && c <= r) A[(size_t)r * ld + c] = acc[m][n][g];
+            if (r <= np && c < np && c <= r && c < clim) A[(size_t)r * ld + c] = acc[m][n][g];
           }
     }
     return;
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
         const int cc = 32 * wc + 16 * n + fcol;
         const int r = r0 + rr, c = c0 + cc;
         if (cc < NB) T[rr * TS + cc] = acc[m][n][g];
-        else if (has_update && r <= np && c < np && c <= r) A[(size_t)r * ld + c] = acc[m][n][g];
+        else if (has_update && r <= np && c < np && c <= r && c < clim) A[(size_t)r * ld + c] = acc[m][n][g];
       }
 
   // ---- factor D in LDS (every workgroup of the column: same bits), two barriers per pivot ----
@@ -741,6 +744,84 @@ __global__ __launch_bounds__(256) void chol_step_kernel(GnState* __restrict__ st
   }
 }
 
+// Two-level schedule for large systems (config 5: 8 743 unknowns).  The one-level loop above streams the whole trailing
+// matrix once per 32-wide panel: n^3 / (6 NB) x 16 B = 56 GB per factorisation at n = 8 743, i.e. HBM-bound.  Panels are
+// therefore grouped into outer blocks of W columns: inside a block the panel steps update only the block's own columns
+// (clim), and ONE launch then applies the block's rank-W update to everything behind it - a quarter of the traffic at
+// W = 128, and f64-MFMA work of useful depth (W / 4 k-steps per tile instead of 8).
+// chol_outer(J0, W): A[r, c] -= L[r, J0:J0+W] L[c, J0:J0+W]^T for every 64x64 tile of the lower triangle with c >= J0 + W
+// (rows up to and including the rhs row np).  Envelope skip as in chol_step.
+__global__ __launch_bounds__(256) void chol_outer_kernel(const GnState* __restrict__ st, double* __restrict__ A, int np,
+                                                         int ld, int J0, int W, const int* __restrict__ tmin32) {
+  if (st->done) return;
+  constexpr int KC = 32, LS = KC + 2;
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (tj > ti) return;
+  const int C0 = J0 + W;
+  const int r0 = C0 + ti * kTile, c0 = C0 + tj * kTile;
+  if (r0 > np || c0 >= np) return;
+  {
+    const int last = np >> 5;
+    const int fr = min(tmin32[min(r0 >> 5, last)], tmin32[min((r0 >> 5) + 1, last)]);
+    const int fc = min(tmin32[min(c0 >> 5, last)], tmin32[min((c0 >> 5) + 1, last)]);
+    if (fr >= C0 || fc >= C0) return;          // these rows have nothing in the block's columns
+  }
+  __shared__ double Li[kTile * LS], Lj[kTile * LS];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wid = t >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int fcol = lane & 15, frow = lane >> 4;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int r = r0 + 32 * wr + 16 * m + frow + 4 * g;
+        const int c = c0 + 32 * wc + 16 * n + fcol;
+        const bool in = r <= np && c < np && c <= r;
+        const double v = A[in ? (size_t)r * ld + c : (size_t)0];
+        acc[m][n][g] = in ? v : 0.0;
+      }
+  const int fi = lane & 15, fk = lane >> 4;
+  for (int q0 = 0; q0 < W; q0 += KC) {
+    __syncthreads();                           // the previous chunk's fragment reads are done
+    for (int k = t; k < kTile * KC; k += 256) {
+      const int r = k / KC, q = k % KC;
+      const double vi = A[(size_t)min(r0 + r, np) * ld + J0 + q0 + q];
+      const double vj = A[(size_t)min(c0 + r, np) * ld + J0 + q0 + q];
+      Li[r * LS + q] = (r0 + r <= np) ? vi : 0.0;
+      Lj[r * LS + q] = (c0 + r < np) ? vj : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k4 = 0; k4 < KC; k4 += 4) {
+      double a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        a[m] = -Li[(32 * wr + 16 * m + fi) * LS + k4 + fk];
+        b[m] = Lj[(32 * wc + 16 * m + fi) * LS + k4 + fk];
+      }
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int r = r0 + 32 * wr + 16 * m + frow + 4 * g;
+        const int c = c0 + 32 * wc + 16 * n + fcol;
+        if (r <= np && c < np && c <= r) A[(size_t)r * ld + c] = acc[m][n][g];
+      }
+}
+
 // back substitution L^T x = y (y = row np), one launch per panel from the last to the first: every
 // workgroup solves the panel's NB unknowns itself (column-oriented, one wave) and then removes them
 // from its 256 entries of y above the panel.  x goes to xs (np doubles).  Used above kBackSmall unknowns.
@@ -780,6 +861,8 @@ __global__ __launch_bounds__(256) void chol_back_kernel(const GnState* __restric
 // the same back substitution as ONE workgroup and ONE launch while y fits in LDS (np <= kBackSmall):
 // panel after panel, y never leaves LDS.
 constexpr int kBackSmall = 2048;
+constexpr int kOuterW = 128;        // outer block width of the two-level LL^T ...
+constexpr int kOuterFrom = 1536;    // ... used above this many unknowns
 
 template <int NB>
 __global__ __launch_bounds__(256) void chol_back_small_kernel(const GnState* __restrict__ st,
@@ -947,16 +1030,16 @@ static int launch_accumulate(int kind, const GnWorkspace& w, const float* Twc, i
   if (cnt <= 0) return MSLAM_OK;
   hipLaunchKernelGGL(gn_edge_setup_kernel, dim3((cnt + 63) / 64), dim3(64), 0, s, w.st, Twc, w.ii_edge + e0,
                      w.jj_edge + e0, cnt, w.econst);
-  dim3 grid(w.S, cnt);
+  dim3 grid((unsigned)w.S * (unsigned)cnt);
   if (kind == 0)
     hipLaunchKernelGGL(gn_accum_kernel<0>, grid, dim3(256), 0, s, w.st, w.econst, w.stream, w.counts, w.chunk_len,
-                       P, w.partial);
+                       P, w.partial, w.S);
   else if (kind == 1)
     hipLaunchKernelGGL(gn_accum_kernel<1>, grid, dim3(256), 0, s, w.st, w.econst, w.stream, w.counts, w.chunk_len,
-                       P, w.partial);
+                       P, w.partial, w.S);
   else
     hipLaunchKernelGGL(gn_accum_kernel<2>, grid, dim3(256), 0, s, w.st, w.econst, w.stream, w.counts, w.chunk_len,
-                       P, w.partial);
+                       P, w.partial, w.S);
   hipLaunchKernelGGL(gn_reduce_kernel, dim3(cnt), dim3(64), 0, s, w.st, w.partial, w.S, Twc, w.ii_edge + e0, e0, E,
                      Hs, gs);
   return check_hip(hipGetLastError(), "gn accumulate launch");
@@ -973,12 +1056,27 @@ static int launch_cholesky(const GnWorkspace& w, hipStream_t s) {
     if (rc) return rc;
     attr_set = true;
   }
-  for (int j0 = -NB; j0 + NB < w.np; j0 += NB) {
+  auto step = [&](int j0, int update, int clim) {
     const int j1 = j0 + NB;
-    const int tiles_r = (w.np - j1 + 1 + kTile - 1) / kTile;           // rows j1..np (np = the rhs row)
-    const int tiles_c = j0 < 0 ? 1 : (w.np - j1 + kTile - 1) / kTile;  // prologue: only the panel column
-    hipLaunchKernelGGL(chol_step_kernel<NB>, dim3(tiles_c, tiles_r), dim3(256), shmem, s, w.st, w.Haug, w.Ldiag,
-                       w.np, w.ld, j0, w.tmin32);
+    const int tiles_r = (w.np - j1 + 1 + kTile - 1) / kTile;                           // rows j1..np (np = the rhs row)
+    const int cend = clim < w.np ? clim : w.np;
+    const int tiles_c = update ? (cend - j1 + kTile - 1) / kTile : 1;                 // no update: only the panel column
+    hipLaunchKernelGGL(chol_step_kernel<NB>, dim3(tiles_c > 0 ? tiles_c : 1, tiles_r), dim3(256), shmem, s, w.st, w.Haug,
+                       w.Ldiag, w.np, w.ld, j0, w.tmin32, update, clim);
+  };
+  // one level (every panel step updates the whole trailing matrix) while that matrix is small: the steps are latency-
+  // bound there; outer blocks of kOuterW columns above (see chol_outer_kernel)
+  const int W = w.np > kOuterFrom ? kOuterW : w.np;
+  step(-NB, 0, w.np);                                        // the first panel
+  for (int J0 = 0; J0 < w.np; J0 += W) {
+    const int jend = J0 + W < w.np ? J0 + W : w.np;
+    for (int j0 = J0; j0 + NB < jend; j0 += NB) step(j0, 1, jend);     // panels inside the block
+    if (jend < w.np) {
+      const int tiles = (w.np - jend + 1 + kTile - 1) / kTile;
+      hipLaunchKernelGGL(chol_outer_kernel, dim3((w.np - jend + kTile - 1) / kTile, tiles), dim3(256), 0, s, w.st, w.Haug,
+                         w.np, w.ld, J0, jend - J0, w.tmin32);
+      step(jend - NB, 0, w.np);                              // the next block's first panel: its columns are up to date
+    }
   }
   if (w.np <= kBackSmall) {
     hipLaunchKernelGGL(chol_back_small_kernel<NB>, dim3(1), dim3(256), 0, s, w.st, w.Haug, w.Ldiag, w.xs, w.np, w.ld);
@@ -1028,7 +1126,7 @@ extern "C" int mslam_gn_begin(const int64_t* ii, const int64_t* jj, int num_pose
                               int num_points, void* workspace, size_t workspace_bytes, void* stream) {
   MSLAM_REQUIRE(num_poses >= 2 && num_edges >= 1, "gn_begin: need >= 2 poses and >= 1 edge");
   MSLAM_REQUIRE(ii && jj, "gn_begin: null pointer");
-  MSLAM_REQUIRE(num_edges <= 65535, "gn_begin: %d edges exceed the grid limit", num_edges);
+  MSLAM_REQUIRE(num_edges <= (1 << 22), "gn_begin: %d edges (the index preparation is quadratic in the edge count)", num_edges);
   GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, 0);
   int rc = gn_check_ws(w.bytes_fixed, workspace, workspace_bytes, "gn_begin");
   if (rc) return rc;
@@ -1053,9 +1151,9 @@ extern "C" int mslam_gn_compact(const float* Xs, const float* Cs, const int64_t*
   GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, edge_count);
   int rc = gn_check_ws(w.bytes, workspace, workspace_bytes, "gn_compact");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_compact_kernel, dim3(w.S, edge_count), dim3(256), 0, (hipStream_t)stream, Xs, Cs,
-                     w.ii_edge + edge_begin, w.jj_edge + edge_begin, idx_ii2jj, valid_match, Q, num_points,
-                     w.chunk_len, C_thresh, Q_thresh, w.stream, w.counts);
+  hipLaunchKernelGGL(gn_compact_kernel, dim3((unsigned)w.S * (unsigned)edge_count), dim3(256), 0, (hipStream_t)stream, Xs,
+                     Cs, w.ii_edge + edge_begin, w.jj_edge + edge_begin, idx_ii2jj, valid_match, Q, num_points,
+                     w.chunk_len, C_thresh, Q_thresh, w.stream, w.counts, w.S);
   return check_hip(hipGetLastError(), "gn_compact launch");
 }
 
