@@ -346,6 +346,13 @@ int mslam_room_pair(const float* ki, const float* kj, int batch, int h, int w, i
                     double cx, double cy, double noise, const double* Wm_3x24, const double* phase_24, float* X1,
                     float* C1, float* D1, float* Q1, float* X2, float* C2, float* D2, float* Q2, void* stream);
 
+/* fp64 GEMM of the retrieval head (Whitener.forward, thirdparty/mast3r/mast3r/retrieval/model.py:62-77; the projector's
+ * Linear layers, model.py:108-151) on the f64 matrix cores:  out f64[M,N] = (A[M,K] - centre[K]) . B + bias[N].
+ * A is f32 or f64 row-major [M,K]; B is f32 or f64, [K,N] row-major (b_transposed = 0) or [N,K] row-major
+ * (b_transposed = 1: an nn.Linear weight); centre f64[K] and bias f64[N] may be NULL. */
+int mslam_gemm_f64(const void* A, int a_is_f32, const void* B, int b_is_f32, int b_transposed, const double* centre,
+                   const double* bias, double* out, int M, int N, int K, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Retrieval database: ASMK with binarised residuals.  Replaces, for one image at a time,
  *   ASMKKernel.aggregate_image + hamming.binarize_and_pack_2D   (thirdparty/mast3r/asmk/asmk/kernel.py:28-42,

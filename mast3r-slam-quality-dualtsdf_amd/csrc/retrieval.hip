@@ -112,6 +112,78 @@ __global__ __launch_bounds__(256) void asmk_search_kernel(
   if (threadIdx.x == 0) scores[img] = total / (double)sqrtf((float)nq);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp64 GEMM of the retrieval head on the f64 matrix cores (the same v_mfma_f64_16x16x4_f64 tile loop as the global GN's
+// LL^T, gn.hip): out[M,N] = (A[M,K] - centre[K]) . B[K,N] (+ bias[N]), A and out row-major, B row-major [K,N].
+//   Whitener.forward (thirdparty/mast3r/mast3r/retrieval/model.py:62-77): fp64 centre + matmul with p (d, d')
+//   the projector's Linear layers (model.py:108-151) with fp64 accumulation of the fp32 operands (exact products)
+// 64x64 tile per workgroup (4 waves, 32x32 each = 2x2 MFMA tiles), K in chunks of 32 through LDS; the centre is
+// subtracted while the A chunk is staged.  768 x 1024 x 1024: 192 workgroups, 3.2 GFLOP.
+// ---------------------------------------------------------------------------------------------------------------------
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(const TA* __restrict__ A, const TB* __restrict__ B,
+                                                       const double* __restrict__ centre, const double* __restrict__ bias,
+                                                       double* __restrict__ out, int M, int N, int K, int lda, int ldb,
+                                                       int b_transposed) {
+  constexpr int T = 64, KC = 32, LS = KC + 2;
+  __shared__ double As[T * LS], Bs[T * LS];          // As[row][k], Bs[col][k]
+  const int r0 = blockIdx.y * T, c0 = blockIdx.x * T;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int fcol = lane & 15, frow = lane >> 4;      // C layout: col = lane & 15, row = (lane >> 4) + 4 reg
+  const int fi = lane & 15, fk = lane >> 4;          // A / B operand: row (col) = lane & 15, k = lane >> 4
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();
+    for (int e = t; e < T * KC; e += 256) {
+      const int rr = e / KC, q = e % KC;             // consecutive threads walk k: contiguous in A and in a transposed B
+      const int k = k0 + q;
+      double va = 0.0, vb = 0.0;
+      if (r0 + rr < M && k < K) va = (double)A[(size_t)(r0 + rr) * lda + k] - (centre ? centre[k] : 0.0);
+      if (b_transposed) { if (c0 + rr < N && k < K) vb = (double)B[(size_t)(c0 + rr) * ldb + k]; }
+      As[rr * LS + q] = va;
+      if (b_transposed) Bs[rr * LS + q] = vb;
+    }
+    if (!b_transposed) {
+      for (int e = t; e < T * KC; e += 256) {
+        const int q = e / T, cc = e % T;             // consecutive threads walk the columns of B's row k
+        const int k = k0 + q;
+        Bs[cc * LS + q] = (c0 + cc < N && k < K) ? (double)B[(size_t)k * ldb + c0 + cc] : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k4 = 0; k4 < KC; k4 += 4) {
+      double a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
+        a[m] = As[(32 * wr + 16 * m + fi) * LS + k4 + fk];
+        b[m] = Bs[(32 * wc + 16 * m + fi) * LS + k4 + fk];
+      }
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int r = r0 + 32 * wr + 16 * m + frow + 4 * g;
+        const int c = c0 + 32 * wc + 16 * n + fcol;
+        if (r < M && c < N) out[(size_t)r * N + c] = acc[m][n][g] + (bias ? bias[c] : 0.0);
+      }
+}
+
 }  // namespace mslam
 
 using namespace mslam;
@@ -141,5 +213,27 @@ extern "C" int mslam_asmk_search(const int32_t* entry_word, const uint32_t* entr
   hipLaunchKernelGGL(asmk_search_kernel, dim3(n_images), dim3(256), 0, (hipStream_t)stream, entry_word, entry_sig,
                      img_start, q_words, q_sig, n_q, sig_words, similarity_threshold, alpha, scores);
   MSLAM_LAUNCH_CHECK("asmk_search");
+  return MSLAM_OK;
+}
+
+extern "C" int mslam_gemm_f64(const void* A, int a_is_f32, const void* B, int b_is_f32, int b_transposed,
+                              const double* centre, const double* bias, double* out, int M, int N, int K, void* stream) {
+  MSLAM_REQUIRE(A && B && out && M > 0 && N > 0 && K > 0, "gemm_f64: bad arguments");
+  const dim3 grid((N + 63) / 64, (M + 63) / 64);
+  const int lda = K, ldb = b_transposed ? K : N;
+  hipStream_t s = (hipStream_t)stream;
+  if (a_is_f32 && b_is_f32)
+    hipLaunchKernelGGL((gemm_f64_kernel<float, float>), grid, dim3(256), 0, s, (const float*)A, (const float*)B, centre, bias,
+                       out, M, N, K, lda, ldb, b_transposed);
+  else if (a_is_f32)
+    hipLaunchKernelGGL((gemm_f64_kernel<float, double>), grid, dim3(256), 0, s, (const float*)A, (const double*)B, centre,
+                       bias, out, M, N, K, lda, ldb, b_transposed);
+  else if (b_is_f32)
+    hipLaunchKernelGGL((gemm_f64_kernel<double, float>), grid, dim3(256), 0, s, (const double*)A, (const float*)B, centre,
+                       bias, out, M, N, K, lda, ldb, b_transposed);
+  else
+    hipLaunchKernelGGL((gemm_f64_kernel<double, double>), grid, dim3(256), 0, s, (const double*)A, (const double*)B, centre,
+                       bias, out, M, N, K, lda, ldb, b_transposed);
+  MSLAM_LAUNCH_CHECK("gemm_f64");
   return MSLAM_OK;
 }

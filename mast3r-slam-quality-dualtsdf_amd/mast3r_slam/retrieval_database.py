@@ -14,8 +14,8 @@ What runs where
     flat device arrays in insertion order (word id, 1024-bit signature, image offsets) and one launch scores every
     database image (a block per image, its entries summed in the reference's order, so scores agree to the last bit of
     the fp64 accumulation apart from the rounding of sim^3).
-  * `prep_features` (lines 24-41): two fp64 whitening GEMMs and the fp32 projector on rocBLAS through torch (plain
-    library GEMMs, 768 x 1024 x 1024), attention = row norm, top-`nfeat` rows.
+  * `prep_features` (lines 24-41): the two fp64 whitening GEMMs and the projector's Linear layers (768 x 1024 x 1024) on the
+    f64 matrix cores (csrc/retrieval.hip::gemm_f64_kernel), attention = row norm, top-`nfeat` rows.
 
 The retrieval checkpoint and its codebook pickle are not available offline: `RetrievalDatabase.from_checkpoint` follows
 thirdparty/mast3r/mast3r/retrieval/processor.py:64-98 for whoever has the files; tests and the synthetic runs construct the
@@ -105,13 +105,34 @@ class RetrievalWeights:
         return cls(wh("prewhiten"), layers, wh("postwhiten"), nfeat=nfeat, residual=residual, device=device)
 
 
+def _gemm_f64(a, b, b_transposed, centre=None, bias=None):
+    """out f64[M,N] = (a[M,K] - centre[K]) . b (+ bias[N]) on the f64 matrix cores (csrc/retrieval.hip); a, b f32 or f64."""
+    a, b = a.contiguous(), b.contiguous()
+    M, K = a.shape
+    N = b.shape[0] if b_transposed else b.shape[1]
+    out = torch.empty((M, N), dtype=torch.float64, device=a.device)
+    cen = None if centre is None else centre.reshape(-1).to(torch.float64).contiguous()
+    bs = None if bias is None else bias.reshape(-1).to(torch.float64).contiguous()
+    rc = _m.lib().mslam_gemm_f64(_m.ptr(a), int(a.dtype == torch.float32), _m.ptr(b), int(b.dtype == torch.float32),
+                                 int(bool(b_transposed)), _m.ptr(cen), _m.ptr(bs), _m.ptr(out), M, N, K, _m.stream_ptr())
+    _m.check(rc, "gemm_f64")
+    return out
+
+
 def _whiten(x, mp):
     """Whitener.forward (retrieval/model.py:62-77, l2norm None): fp64 centre + matmul, cast back to the input type."""
     if mp is None:
         return x
     m, p = mp
-    out = torch.matmul(x.reshape(-1, x.shape[-1]).to(torch.float64) - m, p)
+    out = _gemm_f64(x.reshape(-1, x.shape[-1]), p, False, centre=m)
     return out.reshape(x.shape[:-1] + (p.shape[1],)).to(x.dtype)
+
+
+def _linear(x, weight, bias):
+    """nn.Linear of the projector (retrieval/model.py:108-151; fp32 in the reference): exact products of the fp32
+    operands accumulated in fp64 on the matrix cores, rounded to fp32 once."""
+    out = _gemm_f64(x.reshape(-1, x.shape[-1]), weight, True, bias=bias)
+    return out.reshape(x.shape[:-1] + (weight.shape[0],)).to(x.dtype)
 
 
 class _ArrayOnlyUnpickler(pickle.Unpickler):
@@ -212,7 +233,7 @@ class RetrievalDatabase:
         x = _whiten(backbone_feat.to(self.query_device), w.prewhiten)
         proj = x
         for li, layer in enumerate(w.projector):
-            proj = torch.nn.functional.linear(proj, layer[0], layer[1])
+            proj = _linear(proj, layer[0], layer[1])
             if li + 1 < len(w.projector):
                 proj = torch.nn.functional.gelu(torch.nn.functional.layer_norm(proj, proj.shape[-1:], layer[2], layer[3]))
         if w.residual:

@@ -236,88 +236,129 @@ def test_concurrent_calls_from_two_threads(device):
         assert torch.equal(w_, g_)
 
 
+_FULL = {}
+
+
+def _full_size_pair(device):
+    """The configuration the bench runs - ViT-L encoder (24 x 1024, 16 heads), 12-layer 768-wide decoder, DPT +
+    descriptor heads, one 384x512 pair, seeded random weights - through the torch-fp32 oracle on the host and through the
+    WHOLE chain on the device (the HIP decoder is fed the HIP encoder's own tokens).  Computed once per session (the
+    oracle needs ~10 s of host time)."""
+    if not _FULL:
+        cfg = R.Mast3rConfig()
+        sd, model = _model(cfg, 1, device)
+        g = torch.Generator().manual_seed(4)
+        H, W = 384, 512
+        img1 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+        img2 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+        with torch.inference_mode():
+            f1, p1 = R.encode_image(sd, cfg, img1)
+            f2, p2 = R.encode_image(sd, cfg, img2)
+            d1, d2 = R.decoder(sd, cfg, f1, p1, f2, p2)
+            ref1 = R.downstream_head(sd, cfg, 1, d1, H, W)
+            ref2 = R.downstream_head(sd, cfg, 2, d2, H, W)
+        hf1 = model._encode_image(img1.to(device))[0]
+        hf2 = model._encode_image(img2.to(device))[0]
+        r1, r2, t1, t2 = model.decode_pair(hf1, hf2, H, W, return_tokens=True)
+        _FULL.update(H=H, W=W, f1=f1.numpy(), f2=f2.numpy(), d1=d1[-1].numpy(), d2=d2[-1].numpy(),
+                     ref1={k: v.numpy() for k, v in ref1.items()}, ref2={k: v.numpy() for k, v in ref2.items()},
+                     hf1=hf1.cpu().numpy(), hf2=hf2.cpu().numpy(), t1=t1.cpu().numpy(), t2=t2.cpu().numpy(),
+                     r1={k: v.clone() for k, v in r1.items()}, r2={k: v.clone() for k, v in r2.items()})
+        del model
+    return _FULL
+
+
 def test_full_size_model_matches_oracle(device):
-    """The configuration the bench runs: ViT-L encoder (24 x 1024, 16 heads), 12-layer 768-wide decoder, DPT +
-    descriptor heads, one 384x512 pair, seeded random weights; against the torch-fp32 oracle on the host.
-    Tolerances as stated at the top of this file (bf16 MFMA operands through 36 transformer layers)."""
-    cfg = R.Mast3rConfig()
-    sd, model = _model(cfg, 1, device)
-    g = torch.Generator().manual_seed(4)
-    H, W = 384, 512
-    img1 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
-    img2 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
-    with torch.inference_mode():
-        f1, p1 = R.encode_image(sd, cfg, img1)
-        f2, p2 = R.encode_image(sd, cfg, img2)
-        d1, d2 = R.decoder(sd, cfg, f1, p1, f2, p2)
-        ref1 = R.downstream_head(sd, cfg, 1, d1, H, W)
-        ref2 = R.downstream_head(sd, cfg, 2, d2, H, W)
-    hf1 = model._encode_image(img1.to(device))[0]
-    e_enc = _rel(hf1.cpu().numpy(), f1.numpy())
-    r1, r2, t1, t2 = model.decode_pair(f1.to(device), f2.to(device), H, W, return_tokens=True)
-    e_dec = max(_rel(t1.cpu().numpy(), d1[-1].numpy()), _rel(t2.cpu().numpy(), d2[-1].numpy()))
-    print(f"full-size rel-L2: encoder tokens {e_enc:.4f}, decoder tokens {e_dec:.4f}")
+    """Full-size forward against the torch-fp32 oracle, fully chained on the device: encoder tokens, then decoder tokens
+    and head outputs computed FROM THE HIP ENCODER'S tokens (36 transformer layers of bf16 MFMA operands in a row).
+    Tolerances as stated at the top of this file."""
+    F = _full_size_pair(device)
+    e_enc = max(_rel(F["hf1"], F["f1"]), _rel(F["hf2"], F["f2"]))
+    e_dec = max(_rel(F["t1"], F["d1"]), _rel(F["t2"], F["d2"]))
+    print(f"full-size rel-L2, chained: encoder tokens {e_enc:.4f}, decoder tokens {e_dec:.4f}")
     assert e_enc <= 2e-2 and e_dec <= 2e-2
-    _check_heads(r1, {k: v.numpy() for k, v in ref1.items()})
-    _check_heads(r2, {k: v.numpy() for k, v in ref2.items()})
+    _check_heads(F["r1"], F["ref1"])
+    _check_heads(F["r2"], F["ref2"])
 
 
-CHAIN_IDX_SAME_MIN, CHAIN_IDX_P90_MAX = 0.15, 200   # measured 0.209 / 150: see the docstring and DESIGN.md "(c)"
-
-
-def test_full_size_chain_to_match_indices(device):
-    """SURVEY §7 hard part (a): the whole chain on the device - HIP encode -> HIP decode + heads -> matching.match - against
-    the whole chain of the oracle (torch-fp32 network -> C matching), one 384x512 pair, seeded random weights.  bf16
-    operands can move the INTEGER outputs: this measures by how much and bounds it.  Random weights give smooth but
-    meaningless pointmaps (every pixel's ray is nearly the same), the hardest case for the projection search, so the
-    bounds are loose; what they pin is that the bf16 chain lands on the same matches as the fp32 chain for the bulk
-    of the pixels and that the rest are near misses, not garbage."""
+def _oracle_match(X11, X21, D11, D21, H, W):
     import oracle
     from oracle import matching_py
-    from mast3r_slam import matching
     from mast3r_slam.config import config
 
-    cfg = R.Mast3rConfig()
-    sd, model = _model(cfg, 1, device)
-    g = torch.Generator().manual_seed(11)
-    H, W = 384, 512
-    img1 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
-    img2 = torch.rand(1, 3, H, W, generator=g) * 2 - 1
-    with torch.inference_mode():
-        f1, p1 = R.encode_image(sd, cfg, img1)
-        f2, p2 = R.encode_image(sd, cfg, img2)
-        d1, d2 = R.decoder(sd, cfg, f1, p1, f2, p2)
-        ref1 = R.downstream_head(sd, cfg, 1, d1, H, W)
-        ref2 = R.downstream_head(sd, cfg, 2, d2, H, W)
-    # oracle chain
-    X11, X21 = ref1["pts3d"].numpy(), ref2["pts3d"].numpy()
-    D11, D21 = ref1["desc"].numpy(), ref2["desc"].numpy()
     mc = config["matching"]
     rays, pts, p0 = matching_py.prep_for_iter_proj(X11, X21)
     p, conv = oracle.iter_proj(rays, pts, p0, mc["max_iter"], mc["lambda_init"], mc["convergence_thresh"])
-    p1i, v_ref = matching_py.occlusion_and_trunc(X11, X21, p, conv, mc["dist_thresh"])
+    p1i, v = matching_py.occlusion_and_trunc(X11, X21, p, conv, mc["dist_thresh"])
     p1i = oracle.refine_matches(D11.astype(np.float16), D21.reshape(1, H * W, -1).astype(np.float16), p1i, mc["radius"],
                                 mc["dilation_max"])
-    idx_ref = matching_py.pixel_to_lin(p1i, W)[0]
-    # device chain
-    hf1 = model._encode_image(img1.to(device))[0]
-    hf2 = model._encode_image(img2.to(device))[0]
-    r1, r2 = model.decode_pair(hf1, hf2, H, W)
-    idx, valid = matching.match(r1["pts3d"], r2["pts3d"], r1["desc"], r2["desc"])
-    idx, valid = idx[0].cpu().numpy(), valid[0, :, 0].cpu().numpy()
-    v_ref = v_ref[0]
-    agree_valid = float((valid == v_ref).mean())
-    # random weights: (almost) no pixel passes the 0.1 m occlusion gate on either side, so the integer outputs are
-    # compared for ALL pixels (the search and the descriptor refinement run for every pixel regardless of the gate)
+    return matching_py.pixel_to_lin(p1i, W)[0], v[0]
+
+
+def _index_report(idx, idx_ref, W, mask=None):
     same = idx == idx_ref
-    du = np.abs(idx % W - idx_ref % W)
-    dv = np.abs(idx // W - idx_ref // W)
-    dist = np.maximum(du, dv)[~same]
-    frac_same = float(same.mean())
+    dist = np.maximum(np.abs(idx % W - idx_ref % W), np.abs(idx // W - idx_ref // W))
+    if mask is not None:
+        same, dist = same[mask], dist[mask]
     q = (lambda a, t: float(np.quantile(a, t)) if a.size else 0.0)
-    print(f"chain parity @384x512: valid flags agree {agree_valid:.4f} (valid fraction hip {valid.mean():.4f} / oracle {v_ref.mean():.4f}); "
-          f"identical idx {frac_same:.4f} of {idx.size} pixels; others: Chebyshev pixel distance median {q(dist, 0.5):.1f}, "
-          f"p90 {q(dist, 0.9):.1f}, p99 {q(dist, 0.99):.1f}, max {int(dist.max()) if dist.size else 0}")
-    assert agree_valid >= 0.98
-    assert frac_same >= CHAIN_IDX_SAME_MIN
-    assert q(dist, 0.9) <= CHAIN_IDX_P90_MAX
+    moved = dist[~same]
+    return float(same.mean()), float((dist <= 1).mean()), q(moved, 0.5), q(moved, 0.9), q(moved, 0.99)
+
+
+def test_full_size_chain_report_with_random_weights(device):
+    """A REPORT, not a parity statement: the whole chain on the device (HIP encode -> HIP decode + heads ->
+    matching.match) beside the whole chain of the oracle on one 384x512 pair with seeded RANDOM weights.  Random weights
+    give pointmaps without geometry: no pixel passes the reference's 0.1 m occlusion gate on either side (the valid
+    flags agree because they are all false) and the projection search is chaotic on such input - only about a fifth
+    of the ungated indices coincide and the others are tens of pixels apart.  The asserts are smoke bounds.  What bf16
+    does to the integer outputs in a regime where matches EXIST is measured by
+    test_match_sensitivity_to_the_network_error_field; on trained weights it cannot be measured offline: parity unpinned."""
+    from mast3r_slam import matching
+
+    F = _full_size_pair(device)
+    H, W = F["H"], F["W"]
+    idx_ref, v_ref = _oracle_match(F["ref1"]["pts3d"], F["ref2"]["pts3d"], F["ref1"]["desc"], F["ref2"]["desc"], H, W)
+    idx, valid = matching.match(F["r1"]["pts3d"], F["r2"]["pts3d"], F["r1"]["desc"], F["r2"]["desc"])
+    idx, valid = idx[0].cpu().numpy(), valid[0, :, 0].cpu().numpy()
+    same, near, med, p90, p99 = _index_report(idx, idx_ref, W)
+    print(f"random-weight chain @384x512: valid flags agree {(valid == v_ref).mean():.4f} (valid fraction hip {valid.mean():.4f} / "
+          f"oracle {v_ref.mean():.4f}); identical idx {same:.4f}; moved: median {med:.1f} px, p90 {p90:.1f}, p99 {p99:.1f}")
+    assert (valid == v_ref).mean() >= 0.98 and same >= 0.10
+
+
+SENS_SAME_MIN, SENS_NEAR_MIN, SENS_VALID_MIN = 0.50, 0.90, 0.97      # measured values: DESIGN.md "(c)"; see the docstring
+
+
+def test_match_sensitivity_to_the_network_error_field(device):
+    """What the bf16 network does to the INTEGER match outputs where matches exist.  The error field of the full-size
+    forward - HIP minus oracle, per pixel: relative on the pointmaps (rel-L2 0.015), additive on the unit descriptors
+    (cosine 0.9999) - is transplanted onto a pair with real geometry (the procedural room at 384x512: 98 % of the pixels
+    pass the occlusion gate): the device's matching.match on the PERTURBED pair against the oracle chain on the clean
+    pair.  Bounds (measured, with margin): share of valid pixels whose index is unchanged / within one pixel, agreement of
+    the valid flags.  This is a SENSITIVITY figure under the error field of random weights; parity on trained weights
+    stays unpinned (no checkpoint offline)."""
+    from mast3r_slam import matching, synthetic
+
+    F = _full_size_pair(device)
+    H, W = F["H"], F["W"]
+    pr = synthetic.make_pair(3, 0, h=H, w=W, seed=2)
+    clean = {k: pr[k][None].astype(np.float32) for k in ("X11", "X21", "D11", "D21")}
+    idx_ref, v_ref = _oracle_match(clean["X11"], clean["X21"], clean["D11"], clean["D21"], H, W)
+    pert = {}
+    for name, ref, hip in (("X11", F["ref1"]["pts3d"], F["r1"]["pts3d"]), ("X21", F["ref2"]["pts3d"], F["r2"]["pts3d"])):
+        rel = (hip.cpu().numpy() - ref) / np.maximum(np.linalg.norm(ref, axis=-1, keepdims=True), 1e-12)   # per pixel, relative
+        pert[name] = clean[name] + rel * np.linalg.norm(clean[name], axis=-1, keepdims=True)
+    for name, ref, hip in (("D11", F["ref1"]["desc"], F["r1"]["desc"]), ("D21", F["ref2"]["desc"], F["r2"]["desc"])):
+        d = clean[name] + (hip.cpu().numpy() - ref)
+        pert[name] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    rel_x = _rel(pert["X11"], clean["X11"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
+    idx, valid = matching.match(t(pert["X11"]), t(pert["X21"]), t(pert["D11"]), t(pert["D21"]))
+    idx, valid = idx[0].cpu().numpy(), valid[0, :, 0].cpu().numpy()
+    both = valid & v_ref
+    same, near, med, p90, p99 = _index_report(idx, idx_ref, W, both)
+    print(f"match sensitivity @384x512: pointmap perturbation rel-L2 {rel_x:.4f}; valid flags agree {(valid == v_ref).mean():.4f} "
+          f"(valid fraction {v_ref.mean():.3f}); among valid pixels identical idx {same:.4f}, within 1 px {near:.4f}; "
+          f"moved: median {med:.1f} px, p90 {p90:.1f}, p99 {p99:.1f}")
+    assert 0.005 <= rel_x <= 0.03
+    assert (valid == v_ref).mean() >= SENS_VALID_MIN and same >= SENS_SAME_MIN and near >= SENS_NEAR_MIN
