@@ -346,6 +346,13 @@ int mslam_room_pair(const float* ki, const float* kj, int batch, int h, int w, i
                     double cx, double cy, double noise, const double* Wm_3x24, const double* phase_24, float* X1,
                     float* C1, float* D1, float* Q1, float* X2, float* C2, float* D2, float* Q2, void* stream);
 
+/* cv2.remap(img, mapx, mapy, cv2.INTER_LINEAR) of the calibrated dataset readers (mast3r_slam/dataloader.py:495-496,
+ * Intrinsics.remap) for 8-bit images: src u8[src_h, src_w, channels], maps f32[dst_h, dst_w] (position in src of every
+ * dst pixel), dst u8[dst_h, dst_w, channels]; OpenCV's published fixed-point bilinear (1/32-pixel positions, 2^15
+ * weights, constant border 0).  Parity with the library unpinned (OpenCV is absent): see csrc/undistort.hip. */
+int mslam_remap_bilinear_u8(const uint8_t* src, int src_h, int src_w, int channels, const float* mapx,
+                            const float* mapy, uint8_t* dst, int dst_h, int dst_w, void* stream);
+
 /* fp64 GEMM of the retrieval head (Whitener.forward, thirdparty/mast3r/mast3r/retrieval/model.py:62-77; the projector's
  * Linear layers, model.py:108-151) on the f64 matrix cores:  out f64[M,N] = (A[M,K] - centre[K]) . B + bias[N].
  * A is f32 or f64 row-major [M,K]; B is f32 or f64, [K,N] row-major (b_transposed = 0) or [N,K] row-major

@@ -6,8 +6,9 @@ bytes for PNG; JPEG decoders may differ in the last bit).
 
 What is NOT here, and fails loudly instead of silently doing something else:
 * lens undistortion (`Intrinsics.from_calib` -> cv2.getOptimalNewCameraMatrix / initUndistortRectifyMap / remap,
-  dataloader.py:497-516): OpenCV is not installed and its remap uses 5-bit fixed-point weights that nothing here can
-  pin.  `use_calib: False` runs (every uncalibrated config of the reference) work; asking for calibration raises.
+  dataloader.py:497-516): OpenCV is not installed; since round 3 the three functions are rebuilt from OpenCV's published
+  algorithms (mast3r_slam/undistort.py; the per-image remap, 5-bit fixed-point weights included, as a HIP kernel), so
+  calibrated datasets (TUM / EuRoC / ETH3D / 7-Scenes) load - parity with cv2 itself is UNPINNED, property-tested only.
 * live sources (RealsenseDataset, Webcam) and MP4Dataset (pyrealsense2 / cv2.VideoCapture / torchcodec).
 `SyntheticRoomDataset` is an addition: the procedural room of mast3r_slam.synthetic as a dataset (BASELINE configs 3, 5)."""
 import json
@@ -254,8 +255,9 @@ class SyntheticRoomDataset(MonocularDataset):
 
 
 class Intrinsics:
-    """dataloader.py:476-516.  K_frame (the intrinsics after resize_img's scale + centre crop) is plain arithmetic and is
-    kept; building the undistortion maps is not possible here (see the module docstring)."""
+    """dataloader.py:476-516.  K_frame (the intrinsics after resize_img's scale + centre crop) is plain arithmetic; the
+    undistortion maps and the per-image remap follow OpenCV's published algorithms (mast3r_slam/undistort.py, the remap
+    as a HIP kernel) - OpenCV itself is not installed, so parity with cv2 is UNPINNED (property-tested only)."""
 
     def __init__(self, img_size, W, H, K_orig, K, distortion, mapx, mapy):
         self.img_size = img_size
@@ -267,18 +269,33 @@ class Intrinsics:
         self.K_frame[1, 1] = self.K[1, 1] / scale_h
         self.K_frame[0, 2] = self.K[0, 2] / scale_w - half_crop_w
         self.K_frame[1, 2] = self.K[1, 2] / scale_h - half_crop_h
+        self._remap = None
 
     def remap(self, img):
-        raise NotImplementedError("image undistortion needs OpenCV's remap (not installed); run with use_calib: False")
+        """cv2.remap(img, mapx, mapy, cv2.INTER_LINEAR) (dataloader.py:495-496) on the device."""
+        if self.mapx is None:
+            raise ValueError("Intrinsics.remap: no undistortion maps (constructed for already undistorted images)")
+        if self._remap is None:
+            from mast3r_slam.undistort import DeviceRemap
+
+            self._remap = DeviceRemap(self.mapx, self.mapy)
+        return self._remap(img)
 
     @staticmethod
     def from_calib(img_size, W, H, calib, always_undistort=False):
         if not config["use_calib"] and not always_undistort:
             return None
-        raise NotImplementedError(
-            "calibrated runs need cv2.getOptimalNewCameraMatrix / initUndistortRectifyMap (OpenCV is not installed); "
-            "run with use_calib: False, or construct Intrinsics(img_size, W, H, K, K_opt, distortion, None, None) for "
-            "undistorted images with a known pinhole matrix")
+        from mast3r_slam import undistort as ud
+
+        fx, fy, cx, cy = calib[:4]
+        distortion = np.zeros(4)
+        if len(calib) > 4:
+            distortion = np.array(calib[4:])
+        K = np.array([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]])
+        center = config["dataset"]["center_principle_point"]
+        K_opt = ud.get_optimal_new_camera_matrix(K, distortion, (W, H), 0, (W, H), center_principal_point=center)
+        mapx, mapy = ud.init_undistort_rectify_map(K, distortion, K_opt, (W, H))
+        return Intrinsics(img_size, W, H, K, K_opt, distortion, mapx, mapy)
 
 
 def load_dataset(dataset_path):

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "mslam_tsdf_table_init": [_c_vp, _c_size, ctypes.c_uint64, _c_vp],
     "mslam_tsdf_integrate": [_c_vp, ctypes.c_uint64, _c_vp, _c_vp, _c_vp, _c_int] + [_c_double] * 4 + [_c_int, _c_int, _c_vp, _c_size, _c_vp],
     "mslam_room_pair": [_c_vp, _c_vp] + [_c_int] * 4 + [_c_double] * 5 + [_c_vp] * 10 + [_c_vp],
+    "mslam_remap_bilinear_u8": [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp],
     "mslam_gemm_f64": [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp],
     "mslam_asmk_aggregate": [_c_vp] * 5 + [_c_int] * 5 + [_c_vp],
     "mslam_asmk_search": [_c_vp] * 3 + [_c_int] + [_c_vp] * 2 + [_c_int] * 2 + [_c_float] * 2 + [_c_vp, _c_vp],

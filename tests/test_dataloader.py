@@ -41,14 +41,20 @@ def test_reader_matches_reference(tree, cls):
     assert [os.path.relpath(str(f), root) for f in ds.rgb_files] == list(fx[f"{cls}_sub_files"])
 
 
-def test_calibration_and_live_sources_fail_loudly(tree, monkeypatch):
+def test_calibrated_dataset_builds_its_maps_and_live_sources_fail_loudly(tree, monkeypatch):
+    """use_calib: the TUM reader builds the optimal new camera matrix and the undistortion maps (mast3r_slam/undistort.py,
+    OpenCV's published algorithms - cv2 itself is absent, parity unpinned; the remap kernel needs a device, see
+    tests/test_undistort_gpu.py).  Live / video sources still raise."""
     from mast3r_slam import dataloader as dl
     from mast3r_slam.config import config
 
     fx, root, layout = tree
     monkeypatch.setitem(config, "use_calib", True)
-    with pytest.raises(NotImplementedError, match="OpenCV"):
-        dl.load_dataset(os.path.join(root, layout["TUMDataset"]))
+    ds = dl.load_dataset(os.path.join(root, layout["TUMDataset"]))
+    intr = ds.camera_intrinsics
+    assert ds.has_calib() and intr.mapx.shape == (480, 640) and intr.mapx.dtype == np.float32
+    assert intr.K[0, 2] == 319.5 and intr.K[1, 2] == 239.5          # config.dataset.center_principle_point
+    assert 0.8 * intr.K_orig[0, 0] < intr.K[0, 0] < 1.3 * intr.K_orig[0, 0]
     monkeypatch.setitem(config, "use_calib", False)
     for path in ("realsense", "webcam", "clip.mp4"):
         with pytest.raises(NotImplementedError):
