@@ -50,7 +50,9 @@ def test_update_sequence_matches_the_reference(device, golden_dir):
     n = feats.shape[0]
     for i in range(n):
         frame = types.SimpleNamespace(feat=feats[i])
-        np.testing.assert_allclose(db.prep_features(frame.feat)[0].cpu().numpy(), g[f"local_{i}"], rtol=0, atol=2e-6)
+        # the projector is accumulated in fp64 here (exact products, one rounding); the fixture is the reference's fp32 sgemm
+        # over K = 1024, whose own accumulation error is a few ulp: 1e-6 relative
+        np.testing.assert_allclose(db.prep_features(frame.feat)[0].cpu().numpy(), g[f"local_{i}"], rtol=1e-6, atol=2e-6)
         inds = db.update(frame, True, 3, 0.005)
         assert inds == g[f"inds_{i}"].tolist(), i
         if i > 0:
