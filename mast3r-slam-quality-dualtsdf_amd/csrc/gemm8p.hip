@@ -202,12 +202,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs g) {
         const f32x16 accv = acc[mh][nh][i];
         const int row_base0 = m0 + wr * 128 + mh * 64 + i * 32;
         const int col_base = n0 + wc * 64 + nh * 32;
-        static_for<16>([&](auto r_c) {
-          constexpr int r = decltype(r_c)::value;
-          float x = accv[r] + bias_v[nh];
-          if (g.act == ACT_GELU) x = gelu_erf(x);
-          else if (g.act == ACT_RELU) x = fmaxf(x, 0.0f);
-          tb[((r & 3) + 8 * (r >> 2) + 4 * half) * P8_PATCH_STRIDE + lcol] = x;
+        static_for<8>([&](auto r_c) {
+          constexpr int r = 2 * decltype(r_c)::value;
+          f32x2 x = {accv[r] + bias_v[nh], accv[r + 1] + bias_v[nh]};
+          if (g.act == ACT_GELU) x = gelu_erf2(x);
+          else if (g.act == ACT_RELU) x = __builtin_elementwise_max(x, f32x2{0.0f, 0.0f});
+          tb[((r & 3) + 8 * (r >> 2) + 4 * half) * P8_PATCH_STRIDE + lcol] = x[0];
+          tb[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * half) * P8_PATCH_STRIDE + lcol] = x[1];
         });
 #pragma unroll
         for (int j = 0; j < 2; j++) {
