@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--decode-ahead", type=int, default=0,
                     help="SlamSystem decode_ahead: issue the next group's pair decode on its own stream when at most this "
                          "many decoded frames are left (0: on the tracking stream when none is left)")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="SlamSystem pipeline_depth: frames whose matching + pose solve are enqueued before the oldest verdict is "
+                         "read (0: frame-at-a-time loop)")
     ap.add_argument("--tracking-priority", type=int, default=0,
                     help="run the tracking loop on a stream of this priority (-1 = high) instead of the default stream")
     ap.add_argument("--no-tsdf", action="store_true", help="debug: global + local TSDF off")
@@ -193,7 +196,8 @@ class Session:
         qs = SynchronousQualityService(device=dev, lookup_both=True) if tg is not None else None
         self.system = SlamSystem(self.model, dev, retriever=retriever, frame_group=max(1, args.frame_group),
                                  tsdf_global_cfg=tg, tsdf_refine_cfg=tr, quality_service=qs, decode_ahead=args.decode_ahead,
-                                 backend="inline" if args.no_backend_thread else "thread", shard_channel=channel)
+                                 backend="inline" if args.no_backend_thread else "thread", shard_channel=channel,
+                                 pipeline=args.pipeline_depth > 0, pipeline_depth=max(1, args.pipeline_depth))
         # the stream: RGB frames rendered on the device, resident in HBM before the clock starts
         shp = torch.tensor([[H, W]])
         self.frames = []

@@ -85,7 +85,7 @@ class _BackendThread(threading.Thread):
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
                  backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0,
-                 shard_channel=None, pipeline=True):
+                 shard_channel=None, pipeline=True, pipeline_depth=2):
         """`shard_channel` (mast3r_slam/shard.py): this process is the DRIVER rank of a session whose backend is sharded
         over the ranks of the channel's group - keyframe-pair inference + matching, the global GN (one all-reduce per
         iteration) and the global TSDF's voxels; the other ranks run BackendShard.serve()."""
@@ -95,6 +95,7 @@ class SlamSystem:
         self.tracker.quality_service = quality_service          # main.py:246
         self.shard_channel = shard_channel
         self.pipeline = bool(pipeline)
+        self.pipeline_depth = min(3, max(1, int(pipeline_depth)))     # FrameTracker keeps 4 solver states
         self.factor_graph = FactorGraph(model, self.keyframes, K, device, shard_edges=shard_edges or shard_channel is not None,
                                         channel=shard_channel)
         self.retriever = RecentKeyframes(self.keyframes) if retriever is None else retriever
@@ -125,6 +126,7 @@ class SlamSystem:
         self.enc_stream = torch.cuda.Stream(device=self.device) if self.frame_group > 1 else None
         self._enc_hi = 0
         self._kf_value, self._kf_slope = None, None      # keyframe-rule value of the last tracked frame, its decay per frame
+        self._n_pending = 0                              # frames begun whose verdict is not read yet (pipelined run)
         # decode_ahead = k > 0: the NEXT group's pair decode is issued on a stream of its own as soon as at most k
         # already decoded frames are left in front of the current one, so that it runs beside the per-frame matching /
         # tracking of the current group instead of in front of the next group's first frame (more rows are decoded
@@ -140,9 +142,9 @@ class SlamSystem:
         `release` drops the list's reference to a frame once it has been tracked (keyframes live on in the store), so
         that a long sequence does not keep every pointmap alive.
 
-        `pipeline` (default): in TRACKING mode frame f+1's matching + pose solve are enqueued BEFORE frame f's verdict is
-        read - on the premise "f is tracked and the keyframe stays" (true for ~88 % of the frames) - so the one host
-        wait per frame no longer leaves the device without work.  When the premise fails (new keyframe, tracking
+        `pipeline` (default): in TRACKING mode the matching + pose solve of the next `pipeline_depth` frames are enqueued
+        BEFORE frame f's verdict is read - on the premise "f is tracked and the keyframe stays" (true for ~88 % of the
+        frames) - so the one host wait per frame no longer leaves the device without work.  When the premise fails (new keyframe, tracking
         lost, a solve that needed more than its first chunk of iterations) f+1 is rolled back (nothing of it has
         reached the keyframe store: FrameTracker keeps the fused keyframe in a shadow copy until the verdict is in) and
         begun again from f's real outcome.  Results are bit-identical to the frame-at-a-time loop."""
@@ -157,33 +159,41 @@ class SlamSystem:
                 if release:
                     frames[i] = None
             return out
-        i, pend = start, None                       # pend = (index, handle): begun, verdict not read yet
-        while i < stop or pend is not None:
-            spec = None
-            if i < stop and self.mode == Mode.TRACKING:
+        i, pend = start, []                         # pend = [(index, handle)]: begun, verdict not read yet (oldest first)
+        while i < stop or pend:
+            # run ahead: up to `pipeline_depth` frames begun behind the one whose verdict is read next (the host then
+            # has a frame's worth of enqueue time in hand when the device finishes a frame)
+            while i < stop and self.mode == Mode.TRACKING and len(pend) <= self.pipeline_depth:
+                # speculation that is rarely wrong: the value the keyframe rule compares with its threshold decays
+                # steadily (see _speculative_window); when it says that a frame still in flight will replace the
+                # keyframe, nothing more is begun (or decoded) behind it until that verdict is in
+                self._n_pending = len(pend)
+                if pend and not self._premise_holds(len(pend)):
+                    break
                 if self.frame_group > 1:
                     self._look_ahead(frames, i, stop)
-                spec = (i, self._begin(frames[i]))
-            if pend is not None:
-                k, h = pend
+                pend.append((i, self._begin(frames[i])))
+                i += 1
+            self._n_pending = 0
+            if pend:
+                k, h = pend.pop(0)
                 with self._critical("main"):
                     self.tracker.track_resolve(h)
                     clean = h.kind == "ok" and not h.new_kf and not h.replayed
-                    if spec is not None and not clean:
-                        self.tracker.rollback(spec[1])
-                        self.stats["replayed_frames"] = self.stats.get("replayed_frames", 0) + 1
-                        spec = None
+                    if pend and not clean:              # the premise of everything begun behind it failed: undo, newest first
+                        for _, hh in reversed(pend):
+                            self.tracker.rollback(hh)
+                        self.stats["replayed_frames"] = self.stats.get("replayed_frames", 0) + len(pend)
+                        i = pend[0][0]
+                        pend = []
                     res, add_new_kf = self._end(h)
                 if add_new_kf:
                     self._queue_backend(len(self.keyframes) - 1)
-                if spec is None:
+                if not pend:
                     self.last_T = h.frame.T_WC
                 out.append(res)
                 if release:
                     frames[k] = None
-            pend = spec
-            if spec is not None:
-                i += 1
             elif i < stop and self.mode != Mode.TRACKING:      # INIT / RELOC: frame at a time
                 if self.frame_group > 1:
                     self._look_ahead(frames, i, stop)
@@ -368,6 +378,14 @@ class SlamSystem:
         n = min(B, int(left) - already)
         return max(1, n) if already == 0 else max(0, n)
 
+    def _premise_holds(self, in_flight):
+        """Are the `in_flight` frames whose verdict is still out all predicted to leave the keyframe in place?  (The same
+        prediction that sizes the group decode; unknown decay = right behind a keyframe change: no.)"""
+        if self._kf_value is None or not self._kf_slope or self._kf_slope <= 0.0:
+            return False
+        left = (self._kf_value - config["tracking"]["match_frac_thresh"]) / self._kf_slope
+        return in_flight <= int(left)
+
     def _wait_encoded(self, frame, stream=None, keep=False):
         ev = getattr(frame, "enc_event", None)
         if ev is not None:
@@ -420,7 +438,10 @@ class SlamSystem:
             lo = h + 1                                   # few left: the next group, beside this one's tracking
         else:
             return
-        window = [frames[k] for k in range(lo, min(n, lo + self._speculative_window(B, lo - i)))]
+        # frames begun but not resolved yet (pipelined run) use up part of what the keyframe is expected to last, too
+        window = [frames[k] for k in range(lo, min(n, lo + self._speculative_window(B, lo - i + self._n_pending)))]
+        if not window and lo == i:
+            window = [frames[i]]                         # the frame about to be tracked itself
         if not window:
             return
         for f in window:

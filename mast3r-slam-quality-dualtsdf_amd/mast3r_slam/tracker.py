@@ -30,7 +30,8 @@ class FrameTracker:
         self.keyframes = frames
         self.device = device
         self.reset_idx_f2k()
-        self._slots = [dict(ws=None, status=None, host=None), dict(ws=None, status=None, host=None)]
+        self.N_SLOTS = 4           # solver loop states in flight: the frame being resolved + up to 3 begun behind it
+        self._slots = [dict(ws=None, status=None, host=None) for _ in range(self.N_SLOTS)]
         self._slot = 0
         self._shadow = None        # fused state of the current keyframe that has not been written to the store yet
         self.quality_service = None
@@ -85,7 +86,7 @@ class FrameTracker:
         # one small copy into pinned memory behind an event; the unique count is a scatter instead of torch.unique.
         match_frac = valid_opt.float().mean()
         h.slot = self._slot
-        self._slot ^= 1
+        self._slot = (self._slot + 1) % self.N_SLOTS
         self._cur = h
         if not use_calib:
             T_WCf, T_CkCf, status = self._run_async(False, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, None, None, chunked=True)

@@ -51,7 +51,7 @@ def _frames(ks, device):
                   torch.zeros(H, W, 3)) for i, k in enumerate(ks)]
 
 
-def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=False, pipeline=True):
+def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=False, pipeline=True, depth=2):
     from mast3r_slam.config import config
     from mast3r_slam.slam_system import SlamSystem
 
@@ -64,7 +64,7 @@ def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=Fal
 
         store = SharedKeyframes(None, H, W, buffer=16, device=device)
     system = SlamSystem(model, device, frame_group=frame_group, tsdf_global_cfg=tcfg, backend=backend, keyframes=store,
-                        pipeline=pipeline)
+                        pipeline=pipeline, pipeline_depth=depth)
     frames = _frames(ks, device)
     res = system.run(frames)
     system.shutdown()                                   # drains the backend thread, if any
@@ -247,14 +247,14 @@ def test_backlogged_solves_start_from_the_previous_result(device, eager_keyframe
     system.shutdown()
 
 
-@pytest.mark.parametrize("group,ks", [(1, list(range(0, 60, 3))), (4, list(range(0, 60, 3))),
-                                      (2, [0, 3, 6, 9, 250, 12, 15, 18, 21, 24])])
-def test_pipelined_run_is_bit_identical_to_frame_at_a_time(device, group, ks, eager_keyframes):
-    """SlamSystem.run(pipeline=True) enqueues frame f+1's matching + solve before it reads frame f's verdict and rolls
-    f+1 back when f turns out to be a new keyframe / lost; the frame-at-a-time loop (pipeline=False) is the reference
+@pytest.mark.parametrize("group,ks,depth", [(1, list(range(0, 60, 3)), 2), (4, list(range(0, 60, 3)), 3),
+                                            (2, [0, 3, 6, 9, 250, 12, 15, 18, 21, 24], 2), (2, list(range(0, 60, 3)), 1)])
+def test_pipelined_run_is_bit_identical_to_frame_at_a_time(device, group, ks, depth, eager_keyframes):
+    """SlamSystem.run(pipeline=True) enqueues the matching + solve of up to `depth` frames before it reads frame f's verdict
+    and rolls them back (newest first) when f turns out to be a new keyframe / lost; the frame-at-a-time loop (pipeline=False) is the reference
     order.  Every frame's result, pose and pointmap, the keyframes (poses, fused pointmaps, update counts), the graph and
     the voxel table must agree bit for bit - also across a relocalisation (third sequence)."""
-    sp, mp_, fp, rp = _run(device, ks, group, tsdf=True, pipeline=True)
+    sp, mp_, fp, rp = _run(device, ks, group, tsdf=True, pipeline=True, depth=depth)
     ss, ms, fs, rs = _run(device, ks, group, tsdf=True, pipeline=False)
     assert [(r["mode"], r["new_kf"], r["try_reloc"]) for r in rp] == [(r["mode"], r["new_kf"], r["try_reloc"]) for r in rs]
     for a, b, ra, rb in zip(fp, fs, rp, rs):
