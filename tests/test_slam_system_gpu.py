@@ -247,13 +247,18 @@ def test_backlogged_solves_start_from_the_previous_result(device, eager_keyframe
     system.shutdown()
 
 
-@pytest.mark.parametrize("group,ks,depth", [(1, list(range(0, 60, 3)), 2), (4, list(range(0, 60, 3)), 3),
-                                            (2, [0, 3, 6, 9, 250, 12, 15, 18, 21, 24], 2), (2, list(range(0, 60, 3)), 1)])
-def test_pipelined_run_is_bit_identical_to_frame_at_a_time(device, group, ks, depth, eager_keyframes):
+@pytest.mark.parametrize("group,ks,depth,gate", [(1, list(range(0, 60, 3)), 2, False), (4, list(range(0, 60, 3)), 3, False),
+                                                 (2, [0, 3, 6, 9, 250, 12, 15, 18, 21, 24], 2, False),
+                                                 (2, list(range(0, 60, 3)), 1, False), (4, list(range(0, 90, 3)), 2, True)])
+def test_pipelined_run_is_bit_identical_to_frame_at_a_time(device, group, ks, depth, gate, eager_keyframes, monkeypatch):
     """SlamSystem.run(pipeline=True) enqueues the matching + solve of up to `depth` frames before it reads frame f's verdict
     and rolls them back (newest first) when f turns out to be a new keyframe / lost; the frame-at-a-time loop (pipeline=False) is the reference
     order.  Every frame's result, pose and pointmap, the keyframes (poses, fused pointmaps, update counts), the graph and
     the voxel table must agree bit for bit - also across a relocalisation (third sequence)."""
+    from mast3r_slam.slam_system import SlamSystem
+
+    if not gate:     # speculate blindly: every keyframe change / loss then rolls the frames behind it back
+        monkeypatch.setattr(SlamSystem, "_premise_holds", lambda self, in_flight: True)
     sp, mp_, fp, rp = _run(device, ks, group, tsdf=True, pipeline=True, depth=depth)
     ss, ms, fs, rs = _run(device, ks, group, tsdf=True, pipeline=False)
     assert [(r["mode"], r["new_kf"], r["try_reloc"]) for r in rp] == [(r["mode"], r["new_kf"], r["try_reloc"]) for r in rs]
@@ -269,8 +274,10 @@ def test_pipelined_run_is_bit_identical_to_frame_at_a_time(device, group, ks, de
     assert torch.equal(fa.ii, fb.ii) and torch.equal(fa.jj, fb.jj) and torch.equal(fa.idx_ii2jj, fb.idx_ii2jj)
     va, vb = sp.tsdf_manager.volume.voxels(), ss.tsdf_manager.volume.voxels()
     assert all(np.array_equal(x, y) for x, y in zip(va, vb))
-    # the premise failed exactly where a frame became a keyframe / was lost and another frame stood behind it
-    assert sp.stats.get("replayed_frames", 0) >= len(sp.keyframes) - 2
+    if not gate:   # the premise failed where a frame became a keyframe / was lost and other frames stood behind it
+        assert sp.stats.get("replayed_frames", 0) >= len(sp.keyframes) - 2
+    else:          # with the keyframe-rule prediction as the gate mis-speculation is rare
+        assert sp.stats.get("replayed_frames", 0) <= len(sp.keyframes)
 
 
 def test_pipelined_run_with_solves_that_need_the_second_chunk(device, eager_keyframes, monkeypatch):
