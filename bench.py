@@ -622,8 +622,10 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank == 0:
-        print(f"[bench] frontend loop host time {1e3 * t_enqueued / args.steps:.2f} ms/step of {1e3 * elapsed / args.steps:.2f} ms/step",
-              file=sys.stderr)
+        t_wait = st1.get("verdict_wait_s", 0.0) - st0.get("verdict_wait_s", 0.0)
+        print(f"[bench] frontend loop host time {1e3 * t_enqueued / args.steps:.2f} ms/step of {1e3 * elapsed / args.steps:.2f} ms/step "
+              f"= {1e3 * (t_enqueued - t_wait) / args.steps:.2f} ms/step of enqueue work + {1e3 * t_wait / args.steps:.2f} ms/step waiting for "
+              "the device (tracking verdicts)", file=sys.stderr)
         fps = args.steps * world / elapsed
         new_kf, new_e = kf1 - kf0, e1 - e0
         # network FLOP actually launched inside the timed region (rows of every encoder / decoder+heads call)
@@ -631,7 +633,7 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
         dom_gflop = 2e-9 * M * N * K
         dom_tflops = dom_gflop * 1e3 / avg_us.value if nsamp.value else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_dominant_kernel.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_pmc_dominant_kernel.json")
         if os.path.exists(tpath):   # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the same launch, separate passes (tools/pmc_sum.py)
             try:
                 tj = json.load(open(tpath))
@@ -663,7 +665,10 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
                                  "void_rows": st1["void_rows"] - st0["void_rows"],
                                  "encoder_rows": enc_rows, "decoder_rows_total": dec_rows,
                                  "refine_blocks": st1.get("refine_blocks", 0) - st0.get("refine_blocks", 0),
-                                 "relocalised": st1["relocalised"] - st0["relocalised"]},
+                                 "relocalised": st1["relocalised"] - st0["relocalised"],
+                                 "replayed_frames": st1.get("replayed_frames", 0) - st0.get("replayed_frames", 0),
+                                 "frontend_host_ms_per_step": 1e3 * t_enqueued / args.steps,
+                                 "frontend_wait_for_device_ms_per_step": 1e3 * t_wait / args.steps},
                        "parallelism": f"{world} independent session(s), one per GPU (replicas; {ranks_seen} rank(s) reported by the collective library)"},
             "roofline": {"bound": "mfma", "achieved": dom_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom_tflops / PEAK_BF16_TFLOPS, "traffic": traffic,

@@ -25,6 +25,7 @@ and offers the most recent keyframes as relocalisation candidates."""
 import contextlib
 import queue
 import threading
+import time
 
 import torch
 
@@ -178,7 +179,9 @@ class SlamSystem:
             if pend:
                 k, h = pend.pop(0)
                 with self._critical("main"):
+                    t_wait = time.perf_counter()
                     self.tracker.track_resolve(h)
+                    self.stats["verdict_wait_s"] = self.stats.get("verdict_wait_s", 0.0) + time.perf_counter() - t_wait
                     clean = h.kind == "ok" and not h.new_kf and not h.replayed
                     if pend and not clean:              # the premise of everything begun behind it failed: undo, newest first
                         for _, hh in reversed(pend):

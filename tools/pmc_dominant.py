@@ -25,11 +25,15 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
 if "TCC_HIT_sum" in c:
     out["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
 if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
-    cycles = c["GRBM_GUI_ACTIVE"] / 8.0
-    out["mfma_utilisation_all_1024_simds"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0)
+    # rocprofv3 reports SQ counters once per shader engine (32 rows per dispatch, each a per-SE partial sum) while
+    # GRBM_GUI_ACTIVE / FETCH_SIZE / WRITE_SIZE / TCC_* rows repeat the device total: the mean over rows of an SQ counter is
+    # 1/32 of the device total
+    out["mfma_utilisation_all_1024_simds"] = 32.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 1024.0)
     w = c.get("SQ_WAVE_CYCLES", 0.0)
     if w:
         out["wave_time_split"] = {"parked_waitcnt_or_barrier": c["SQ_WAIT_ANY"] / w,
                                   "issuing": c["SQ_ACTIVE_INST_ANY"] / w,
                                   "issue_stall": (c["SQ_WAIT_INST_ANY"] - 0.0) / w}
+    out["note"] = ("per_dispatch_mean is the mean over rocprofv3's rows: SQ_* device totals are 32 x the value listed "
+                   "(per-shader-engine partial sums), the other counters are device totals")
 print(json.dumps(out, indent=1))
