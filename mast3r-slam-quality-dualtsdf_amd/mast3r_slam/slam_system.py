@@ -162,59 +162,63 @@ class SlamSystem:
             return out
         i, pend = start, []                         # pend = [(index, handle)]: begun, verdict not read yet (oldest first)
         while i < stop or pend:
-            # run ahead: up to `pipeline_depth` frames begun behind the one whose verdict is read next (the host then
-            # has a frame's worth of enqueue time in hand when the device finishes a frame)
-            while i < stop and self.mode == Mode.TRACKING and len(pend) <= self.pipeline_depth:
-                # speculation that is rarely wrong: the value the keyframe rule compares with its threshold decays
-                # steadily (see _speculative_window); when it says that a frame still in flight will replace the
-                # keyframe, nothing more is begun (or decoded) behind it until that verdict is in
-                self._n_pending = len(pend)
-                if pend and not self._premise_holds(len(pend)):
-                    break
-                if self.frame_group > 1:
-                    self._look_ahead(frames, i, stop)
-                pend.append((i, self._begin(frames[i])))
-                i += 1
-            self._n_pending = 0
-            if pend:
-                k, h = pend.pop(0)
-                with self._critical("main"):
-                    t_wait = time.perf_counter()
-                    self.tracker.track_resolve(h)
-                    self.stats["verdict_wait_s"] = self.stats.get("verdict_wait_s", 0.0) + time.perf_counter() - t_wait
-                    clean = h.kind == "ok" and not h.new_kf and not h.replayed
-                    if pend and not clean:              # the premise of everything begun behind it failed: undo, newest first
-                        for _, hh in reversed(pend):
-                            self.tracker.rollback(hh)
-                        self.stats["replayed_frames"] = self.stats.get("replayed_frames", 0) + len(pend)
-                        i = pend[0][0]
-                        pend = []
-                    res, add_new_kf = self._end(h)
-                if add_new_kf:
-                    self._queue_backend(len(self.keyframes) - 1)
-                if not pend:
-                    self.last_T = h.frame.T_WC
-                out.append(res)
-                if release:
-                    frames[k] = None
-            elif i < stop and self.mode != Mode.TRACKING:      # INIT / RELOC: frame at a time
+            if not pend and self.mode != Mode.TRACKING:        # INIT / RELOC: frame at a time
                 if self.frame_group > 1:
                     self._look_ahead(frames, i, stop)
                 out.append(self.step(frames[i]))
                 if release:
                     frames[i] = None
                 i += 1
+                continue
+            add_new_kf = False
+            # ONE hand-over section per iteration, as in the frame-at-a-time loop (every section boundary is also a
+            # dependency between the tracking and the backend stream): begin the frames that may run ahead, then read
+            # the oldest verdict
+            with self._critical("main"):
+                self._apply_commits()
+                # run ahead: up to `pipeline_depth` frames begun behind the one whose verdict is read next (the host then
+                # has a frame's worth of enqueue time in hand when the device finishes a frame)
+                while i < stop and self.mode == Mode.TRACKING and len(pend) <= self.pipeline_depth:
+                    # speculation that is rarely wrong: the value the keyframe rule compares with its threshold decays
+                    # steadily (see _speculative_window); when it says that a frame still in flight will replace the
+                    # keyframe, nothing more is begun (or decoded) behind it until that verdict is in
+                    self._n_pending = len(pend)
+                    if pend and not self._premise_holds(len(pend)):
+                        break
+                    if self.frame_group > 1:
+                        self._look_ahead(frames, i, stop)
+                    pend.append((i, self._begin(frames[i])))
+                    i += 1
+                self._n_pending = 0
+                k, h = pend.pop(0)
+                t_wait = time.perf_counter()
+                self.tracker.track_resolve(h)
+                self.stats["verdict_wait_s"] = self.stats.get("verdict_wait_s", 0.0) + time.perf_counter() - t_wait
+                clean = h.kind == "ok" and not h.new_kf and not h.replayed
+                if pend and not clean:              # the premise of everything begun behind it failed: undo, newest first
+                    for _, hh in reversed(pend):
+                        self.tracker.rollback(hh)
+                    self.stats["replayed_frames"] = self.stats.get("replayed_frames", 0) + len(pend)
+                    i = pend[0][0]
+                    pend = []
+                res, add_new_kf = self._end(h)
+            if add_new_kf:
+                self._queue_backend(len(self.keyframes) - 1)
+            if not pend:
+                self.last_T = h.frame.T_WC
+            out.append(res)
+            if release:
+                frames[k] = None
         return out
 
     def _begin(self, frame):
-        """First half of step() for a frame in TRACKING mode: everything enqueued, verdict not read."""
+        """First half of step() for a frame in TRACKING mode: everything enqueued, verdict not read.  Called inside the
+        hand-over section."""
         self._wait_encoded(frame)
         self._wait_decoded(frame)
         if self.last_T is not None:
             frame.T_WC = Sim3(self.last_T.data.clone())
-        with self._critical("main"):
-            self._apply_commits()
-            h = self.tracker.track_begin(frame)
+        h = self.tracker.track_begin(frame)
         self.last_T = frame.T_WC                    # optimistic: the next frame starts from this one's solved pose
         return h
 
