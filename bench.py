@@ -94,9 +94,9 @@ def parse():
     ap.add_argument("--decode-ahead", type=int, default=0,
                     help="SlamSystem decode_ahead: issue the next group's pair decode on its own stream when at most this "
                          "many decoded frames are left (0: on the tracking stream when none is left)")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
+    ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="SlamSystem pipeline_depth: frames whose matching + pose solve are enqueued before the oldest verdict is "
-                         "read (0: frame-at-a-time loop)")
+                         "read (0 = the default: frame-at-a-time loop, which measures faster end to end: DESIGN.md)")
     ap.add_argument("--tracking-priority", type=int, default=0,
                     help="run the tracking loop on a stream of this priority (-1 = high) instead of the default stream")
     ap.add_argument("--no-tsdf", action="store_true", help="debug: global + local TSDF off")

@@ -86,7 +86,7 @@ class _BackendThread(threading.Thread):
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
                  backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0,
-                 shard_channel=None, pipeline=True, pipeline_depth=2):
+                 shard_channel=None, pipeline=False, pipeline_depth=1):
         """`shard_channel` (mast3r_slam/shard.py): this process is the DRIVER rank of a session whose backend is sharded
         over the ranks of the channel's group - keyframe-pair inference + matching, the global GN (one all-reduce per
         iteration) and the global TSDF's voxels; the other ranks run BackendShard.serve()."""
@@ -143,12 +143,19 @@ class SlamSystem:
         `release` drops the list's reference to a frame once it has been tracked (keyframes live on in the store), so
         that a long sequence does not keep every pointmap alive.
 
-        `pipeline` (default): in TRACKING mode the matching + pose solve of the next `pipeline_depth` frames are enqueued
-        BEFORE frame f's verdict is read - on the premise "f is tracked and the keyframe stays" (true for ~88 % of the
-        frames) - so the one host wait per frame no longer leaves the device without work.  When the premise fails (new keyframe, tracking
+        `pipeline` (off by default, see below): in TRACKING mode the matching + pose solve of the next `pipeline_depth`
+        frames are enqueued BEFORE frame f's verdict is read - on the premise "f is tracked and the keyframe stays" (true
+        for ~88 % of the frames) - so the one host wait per frame no longer leaves the tracking stream without work.  When the premise fails (new keyframe, tracking
         lost, a solve that needed more than its first chunk of iterations) f+1 is rolled back (nothing of it has
         reached the keyframe store: FrameTracker keeps the fused keyframe in a shadow copy until the verdict is in) and
-        begun again from f's real outcome.  Results are bit-identical to the frame-at-a-time loop."""
+        begun again from f's real outcome.  Results are bit-identical to the frame-at-a-time loop.
+
+        MEASURED (1 000-frame stream, same box, DESIGN.md "Round 3: the tracking loop"): the frontend's host work drops
+        from 5.7 to 2.0-2.9 ms per frame, but the JOB gets slower (138 -> 133 frames/s at depth 1, 116-126 at depth 2 or with
+        one hand-over section per iteration): a tracking stream that never runs dry takes the device away from the
+        backend stream, the frontend finishes early and the backend drains its backlog alone - a single dependent
+        chain of short kernels with a launch bubble behind each.  The frame-at-a-time loop interleaves the two by
+        itself (the device works on the backend while the host reads a verdict), so it stays the default."""
         out = []
         stop = len(frames) if stop is None else min(stop, len(frames))
         self._enc_hi = max(self._enc_hi, start)
@@ -162,63 +169,59 @@ class SlamSystem:
             return out
         i, pend = start, []                         # pend = [(index, handle)]: begun, verdict not read yet (oldest first)
         while i < stop or pend:
-            if not pend and self.mode != Mode.TRACKING:        # INIT / RELOC: frame at a time
+            # run ahead: up to `pipeline_depth` frames begun behind the one whose verdict is read next (the host then
+            # has a frame's worth of enqueue time in hand when the device finishes a frame)
+            while i < stop and self.mode == Mode.TRACKING and len(pend) <= self.pipeline_depth:
+                # speculation that is rarely wrong: the value the keyframe rule compares with its threshold decays
+                # steadily (see _speculative_window); when it says that a frame still in flight will replace the
+                # keyframe, nothing more is begun (or decoded) behind it until that verdict is in
+                self._n_pending = len(pend)
+                if pend and not self._premise_holds(len(pend)):
+                    break
+                if self.frame_group > 1:
+                    self._look_ahead(frames, i, stop)
+                pend.append((i, self._begin(frames[i])))
+                i += 1
+            self._n_pending = 0
+            if pend:
+                k, h = pend.pop(0)
+                with self._critical("main"):
+                    t_wait = time.perf_counter()
+                    self.tracker.track_resolve(h)
+                    self.stats["verdict_wait_s"] = self.stats.get("verdict_wait_s", 0.0) + time.perf_counter() - t_wait
+                    clean = h.kind == "ok" and not h.new_kf and not h.replayed
+                    if pend and not clean:              # the premise of everything begun behind it failed: undo, newest first
+                        for _, hh in reversed(pend):
+                            self.tracker.rollback(hh)
+                        self.stats["replayed_frames"] = self.stats.get("replayed_frames", 0) + len(pend)
+                        i = pend[0][0]
+                        pend = []
+                    res, add_new_kf = self._end(h)
+                if add_new_kf:
+                    self._queue_backend(len(self.keyframes) - 1)
+                if not pend:
+                    self.last_T = h.frame.T_WC
+                out.append(res)
+                if release:
+                    frames[k] = None
+            elif i < stop and self.mode != Mode.TRACKING:      # INIT / RELOC: frame at a time
                 if self.frame_group > 1:
                     self._look_ahead(frames, i, stop)
                 out.append(self.step(frames[i]))
                 if release:
                     frames[i] = None
                 i += 1
-                continue
-            add_new_kf = False
-            # ONE hand-over section per iteration, as in the frame-at-a-time loop (every section boundary is also a
-            # dependency between the tracking and the backend stream): begin the frames that may run ahead, then read
-            # the oldest verdict
-            with self._critical("main"):
-                self._apply_commits()
-                # run ahead: up to `pipeline_depth` frames begun behind the one whose verdict is read next (the host then
-                # has a frame's worth of enqueue time in hand when the device finishes a frame)
-                while i < stop and self.mode == Mode.TRACKING and len(pend) <= self.pipeline_depth:
-                    # speculation that is rarely wrong: the value the keyframe rule compares with its threshold decays
-                    # steadily (see _speculative_window); when it says that a frame still in flight will replace the
-                    # keyframe, nothing more is begun (or decoded) behind it until that verdict is in
-                    self._n_pending = len(pend)
-                    if pend and not self._premise_holds(len(pend)):
-                        break
-                    if self.frame_group > 1:
-                        self._look_ahead(frames, i, stop)
-                    pend.append((i, self._begin(frames[i])))
-                    i += 1
-                self._n_pending = 0
-                k, h = pend.pop(0)
-                t_wait = time.perf_counter()
-                self.tracker.track_resolve(h)
-                self.stats["verdict_wait_s"] = self.stats.get("verdict_wait_s", 0.0) + time.perf_counter() - t_wait
-                clean = h.kind == "ok" and not h.new_kf and not h.replayed
-                if pend and not clean:              # the premise of everything begun behind it failed: undo, newest first
-                    for _, hh in reversed(pend):
-                        self.tracker.rollback(hh)
-                    self.stats["replayed_frames"] = self.stats.get("replayed_frames", 0) + len(pend)
-                    i = pend[0][0]
-                    pend = []
-                res, add_new_kf = self._end(h)
-            if add_new_kf:
-                self._queue_backend(len(self.keyframes) - 1)
-            if not pend:
-                self.last_T = h.frame.T_WC
-            out.append(res)
-            if release:
-                frames[k] = None
         return out
 
     def _begin(self, frame):
-        """First half of step() for a frame in TRACKING mode: everything enqueued, verdict not read.  Called inside the
-        hand-over section."""
+        """First half of step() for a frame in TRACKING mode: everything enqueued, verdict not read."""
         self._wait_encoded(frame)
         self._wait_decoded(frame)
         if self.last_T is not None:
             frame.T_WC = Sim3(self.last_T.data.clone())
-        h = self.tracker.track_begin(frame)
+        with self._critical("main"):
+            self._apply_commits()
+            h = self.tracker.track_begin(frame)
         self.last_T = frame.T_WC                    # optimistic: the next frame starts from this one's solved pose
         return h
 

@@ -51,7 +51,7 @@ def _frames(ks, device):
                   torch.zeros(H, W, 3)) for i, k in enumerate(ks)]
 
 
-def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=False, pipeline=True, depth=2):
+def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=False, pipeline=False, depth=2):
     from mast3r_slam.config import config
     from mast3r_slam.slam_system import SlamSystem
 
