@@ -36,6 +36,8 @@ class FactorGraph:
         self.K = K
         self.last_unique_kf_idx = None
         self.shard_edges = shard_edges
+        self.reuse_tracking_decode = True
+        self.reused_rows = 0
         # driver / shard roles of one session (mast3r_slam/shard.py): the driver announces its sharded calls so that the
         # shard ranks make them too; None = every rank calls the sharded methods itself (SPMD)
         self.channel = channel
@@ -59,7 +61,20 @@ class FactorGraph:
         if self.shard_edges and torch.distributed.is_available() and torch.distributed.is_initialized():
             res = match_symmetric_sharded(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j, group=self.group)
         else:
-            res = mast3r_match_symmetric(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
+            # a direction tracking has already decoded (the new keyframe against the keyframe it was tracked on) is taken
+            # over instead of being decoded again: same bits (rows of a batch do not depend on the batch), one row less
+            cached, B = {}, len(kf_ii)
+            if self.reuse_tracking_decode:
+                for e, (a, b) in enumerate(zip(kf_ii, kf_jj)):
+                    for row, (src, dst) in ((e, (a, b)), (B + e, (b, a))):
+                        pd = getattr(src, "pair_decode", None)
+                        if pd is not None and pd[0] == int(dst.frame_id) and a is not b:
+                            cached[row] = pd[1]
+            res = mast3r_match_symmetric(self.model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j, cached=cached or None)
+            self.reused_rows += len(cached)
+        for kf in kf_ii + kf_jj:          # 46 MB per keyframe at 512x384: consumed (or useless) from here on
+            if getattr(kf, "pair_decode", None) is not None:
+                kf.pair_decode = None
         return self.add_matched_factors(ii, jj, *res, min_match_frac=min_match_frac, is_reloc=is_reloc)
 
     @property

@@ -72,16 +72,40 @@ def mast3r_symmetric_inference(model, frame_i, frame_j):
 
 
 @torch.inference_mode()
-def mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
+def mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j, cached=None):
     """mast3r_utils.py:83-115.  The reference loops over the B edges in Python (one decoder call per
-    edge and direction); here all edges and both directions are ONE batched native call."""
+    edge and direction); here all edges and both directions are ONE batched native call.
+
+    `cached` (optional): {row: (X, C, D, Q)} - two-view results (res11, res21 stacked, as mast3r_asymmetric_inference
+    returns them) that already exist for rows of the batch: row e < B is decoder(feat_i[e], feat_j[e]), row B + e is
+    decoder(feat_j[e], feat_i[e]).  Tracking has computed exactly the second kind for the consecutive edge of a new
+    keyframe (the frame against the keyframe it was tracked on); rows of a batch do not depend on the batch, so taking
+    them over changes no bit and saves one of the ~8 decoder + head rows of a keyframe's backend task."""
     H, W = _hw(shape_i[0])
     B = feat_i.shape[0]
     # both directions of all B edges in ONE native call of batch 2B: rows [0, B) decode (i, j), rows [B, 2B) decode
     # (j, i); results are bitwise those of separate calls (no arithmetic depends on the batch size)
-    ra, rb = model.decode_pair(torch.cat((feat_i, feat_j)), torch.cat((feat_j, feat_i)), H, W)
-    pick = lambda k: torch.stack((ra[k][:B], rb[k][:B], ra[k][B:], rb[k][B:]))      # order [ii, ji, jj, ij]
-    return downsample(pick("pts3d"), pick("conf"), pick("desc"), pick("desc_conf"))  # X: (4, B, H, W, 3)
+    f1, f2 = torch.cat((feat_i, feat_j)), torch.cat((feat_j, feat_i))
+    keys = ("pts3d", "conf", "desc", "desc_conf")
+    if not cached:
+        ra, rb = model.decode_pair(f1, f2, H, W)
+        pick = lambda k: torch.stack((ra[k][:B], rb[k][:B], ra[k][B:], rb[k][B:]))      # order [ii, ji, jj, ij]
+        return downsample(pick("pts3d"), pick("conf"), pick("desc"), pick("desc_conf"))  # X: (4, B, H, W, 3)
+    keep = [r for r in range(2 * B) if r not in cached]
+    out = []
+    if keep:
+        sel = torch.tensor(keep, device=f1.device)
+        ra, rb = model.decode_pair(f1[sel].contiguous(), f2[sel].contiguous(), H, W)
+        part = downsample(*(torch.stack((ra[k], rb[k])) for k in keys))                  # each (2, n_keep, H', W'[, c])
+    some = cached[next(iter(cached))]
+    for q in range(4):
+        full = torch.empty((2, 2 * B) + tuple(some[q].shape[1:]), dtype=some[q].dtype, device=some[q].device)
+        if keep:
+            full[:, sel] = part[q]
+        for r, res in cached.items():
+            full[:, r] = res[q]
+        out.append(torch.stack((full[0, :B], full[1, :B], full[0, B:], full[1, B:])))    # [ii, ji, jj, ij]
+    return tuple(out)
 
 
 @torch.inference_mode()
@@ -94,9 +118,9 @@ def mast3r_inference_mono(model, frame):
     return X[0].reshape(-1, 3), C[0].reshape(-1, 1)
 
 
-def mast3r_match_symmetric(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j):
-    """mast3r_utils.py:142-180."""
-    X, C, D, Q = mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j)
+def mast3r_match_symmetric(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j, cached=None):
+    """mast3r_utils.py:142-180 (`cached`: see mast3r_decode_symmetric_batch)."""
+    X, C, D, Q = mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, shape_j, cached=cached)
     b = X.shape[1]
     Xii, Xji, Xjj, Xij = X[0], X[1], X[2], X[3]
     Dii, Dji, Djj, Dij = D[0], D[1], D[2], D[3]
@@ -146,17 +170,22 @@ def mast3r_asymmetric_inference_group(model, frames, keyframe):
 @torch.inference_mode()
 def mast3r_asymmetric_inference(model, frame_i, frame_j):
     """mast3r_utils.py:183-206.  A result left by mast3r_asymmetric_inference_group for this very pair is used
-    once instead of being recomputed."""
+    once instead of being recomputed.  The result stays attached to frame_i (`pair_decode`, tagged with frame_j's id): if
+    frame_i becomes a keyframe, the backend's symmetric inference of the edge (frame_j, frame_i) takes this direction over."""
     stash = getattr(frame_i, "decoded", None)
     if stash is not None:
         frame_i.decoded = None
         if stash[0] == int(frame_j.frame_id):   # a keyframe's features never change once encoded
+            frame_i.pair_decode = stash
             return stash[1]
     _ensure_feat(model, frame_i)
     _ensure_feat(model, frame_j)
     res11, res21 = decoder(model, frame_i.feat, frame_j.feat, frame_i.pos, frame_j.pos, frame_i.img_true_shape,
                            frame_j.img_true_shape)
-    return downsample(*_stack([res11, res21]))
+    out = downsample(*_stack([res11, res21]))
+    if hasattr(frame_j, "frame_id"):
+        frame_i.pair_decode = (int(frame_j.frame_id), out)
+    return out
 
 
 def mast3r_match_asymmetric(model, frame_i, frame_j, idx_i2j_init=None):

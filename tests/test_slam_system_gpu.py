@@ -51,7 +51,7 @@ def _frames(ks, device):
                   torch.zeros(H, W, 3)) for i, k in enumerate(ks)]
 
 
-def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=False, pipeline=False, depth=2):
+def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=False, pipeline=False, depth=2, reuse=True):
     from mast3r_slam.config import config
     from mast3r_slam.slam_system import SlamSystem
 
@@ -65,6 +65,7 @@ def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=Fal
         store = SharedKeyframes(None, H, W, buffer=16, device=device)
     system = SlamSystem(model, device, frame_group=frame_group, tsdf_global_cfg=tcfg, backend=backend, keyframes=store,
                         pipeline=pipeline, pipeline_depth=depth)
+    system.factor_graph.reuse_tracking_decode = reuse
     frames = _frames(ks, device)
     res = system.run(frames)
     system.shutdown()                                   # drains the backend thread, if any
@@ -297,3 +298,25 @@ def test_pipelined_run_with_solves_that_need_the_second_chunk(device, eager_keyf
     for i in range(len(ref[0].keyframes)):
         ka, kb = ref[0].keyframes[i], got[0].keyframes[i]
         assert torch.equal(ka.T_WC.data, kb.T_WC.data) and torch.equal(ka.X_canon, kb.X_canon) and torch.equal(ka.C, kb.C)
+
+
+@pytest.mark.parametrize("group", [1, 4])
+def test_backend_takes_over_the_direction_tracking_decoded(device, group, eager_keyframes):
+    """The consecutive edge (previous keyframe, new keyframe) needs decoder(new, previous) - exactly the two-view forward
+    tracking ran for the frame that became the new keyframe.  The backend takes that row over instead of decoding it
+    again (rows of a batch do not depend on the batch): one decoder + heads row less per keyframe, not a bit changed."""
+    ks = list(range(0, 60, 3))
+    sa, ma, fa, ra = _run(device, ks, group, tsdf=True, reuse=True)
+    sb, mb, fb, rb = _run(device, ks, group, tsdf=True, reuse=False)
+    n_kf = len(sa.keyframes)
+    assert n_kf == len(sb.keyframes) >= 3
+    assert sa.factor_graph.reused_rows == n_kf - 1 and sb.factor_graph.reused_rows == 0
+    assert mb.dec_rows - ma.dec_rows == n_kf - 1
+    for a, b in zip(fa, fb):
+        assert torch.equal(a.T_WC.data, b.T_WC.data)
+    for i in range(n_kf):
+        assert torch.equal(sa.keyframes[i].T_WC.data, sb.keyframes[i].T_WC.data)
+        assert getattr(sa.keyframes[i], "pair_decode", None) is None          # released once the task has used it
+    ga, gb = sa.factor_graph, sb.factor_graph
+    for k in ("ii", "jj", "idx_ii2jj", "idx_jj2ii", "valid_match_j", "valid_match_i", "Q_ii2jj", "Q_jj2ii"):
+        assert torch.equal(getattr(ga, k), getattr(gb, k)), k
