@@ -62,7 +62,7 @@ class _BackendThread(threading.Thread):
     def run(self):
         dev = self.system.device
         torch.cuda.set_device(dev)
-        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        with torch.cuda.stream(torch.cuda.Stream(device=dev, priority=self.system.backend_priority)):
             while True:
                 task = self.q.get()
                 try:
@@ -86,7 +86,7 @@ class _BackendThread(threading.Thread):
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
                  backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0,
-                 shard_channel=None, pipeline=False, pipeline_depth=1):
+                 shard_channel=None, pipeline=False, pipeline_depth=1, backend_priority=0):
         """`shard_channel` (mast3r_slam/shard.py): this process is the DRIVER rank of a session whose backend is sharded
         over the ranks of the channel's group - keyframe-pair inference + matching, the global GN (one all-reduce per
         iteration) and the global TSDF's voxels; the other ranks run BackendShard.serve()."""
@@ -95,6 +95,7 @@ class SlamSystem:
         self.tracker = FrameTracker(model, self.keyframes, device)
         self.tracker.quality_service = quality_service          # main.py:246
         self.shard_channel = shard_channel
+        self.backend_priority = int(backend_priority)      # HIP stream priority of the backend thread's stream (-1 = high)
         self.pipeline = bool(pipeline)
         self.pipeline_depth = min(3, max(1, int(pipeline_depth)))     # FrameTracker keeps 4 solver states
         self.factor_graph = FactorGraph(model, self.keyframes, K, device, shard_edges=shard_edges or shard_channel is not None,
