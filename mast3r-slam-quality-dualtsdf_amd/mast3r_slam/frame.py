@@ -119,6 +119,17 @@ class KeyframeStore:
         self._kfs = []
         self._stamps = []      # per keyframe: bumped whenever its pointmap / confidence may have changed
         self._clock = 0
+        self.K = None          # calibrated runs: SharedKeyframes.set_intrinsics (frame.py:325-333)
+
+    def set_intrinsics(self, K):
+        assert config["use_calib"]
+        self.K = K
+        for kf in self._kfs:
+            kf.K = K
+
+    def get_intrinsics(self):
+        assert config["use_calib"]
+        return self.K
 
     def __len__(self):
         return len(self._kfs)
@@ -134,6 +145,8 @@ class KeyframeStore:
         """Copy-in, as SharedKeyframes does (frame.py:312-314): later updates of the keyframe (pointmap fusion, backend
         poses) do not reach back into the caller's Frame object.  Tensors are shared, not cloned."""
         self._kfs.append(copy.copy(frame))
+        if self.K is not None and config["use_calib"]:
+            self._kfs[-1].K = self.K        # a keyframe read from the store carries the intrinsics (frame.py:262-263)
         self._stamps.append(0)
         self.touch(len(self._kfs) - 1)
 

@@ -109,7 +109,10 @@ def driver_and_shards(rank, world, dev, model, H, W):
     from mast3r_slam.slam_system import SlamSystem
     from mast3r_slam.synthetic_gpu import PoseProximityRetriever
 
-    stride, n_frames = 3, 36
+    # the camera path: steady motion, one frame from the other side of the room (tracking is lost there and the session
+    # relocalises against the map: main.py:28-71 through the sharded add_factors / solve), steady motion again
+    ks = list(range(0, 66, 3)) + [250] + list(range(66, 108, 3))
+    n_frames = len(ks)
     saved = config["tracking"]["match_frac_thresh"]
     config["tracking"]["match_frac_thresh"] = 0.72          # a keyframe every ~7 frames at this resolution
     tcfg = dict(config["tsdf_global"], enabled=True, hash_capacity=1 << 16, pre_icp_iters=0, max_iterations=1,
@@ -118,11 +121,11 @@ def driver_and_shards(rank, world, dev, model, H, W):
 
     def session(channel):
         torch.manual_seed(0)
-        retr = PoseProximityRetriever(lambda fr: stride * int(fr.frame_id), 1000)
+        retr = PoseProximityRetriever(lambda fr: ks[int(fr.frame_id)], 1000)
         system = SlamSystem(model, dev, retriever=retr, frame_group=2, tsdf_global_cfg=tcfg, backend="inline",
                             shard_channel=channel)
         shp = torch.tensor([[H, W]])
-        img = model.room.rgb(stride * torch.arange(n_frames, device=dev))
+        img = model.room.rgb(torch.tensor(ks, device=dev))
         frames = [Frame(j, img[j:j + 1].clone(), shp, shp, None) for j in range(n_frames)]
         results = system.run(frames)
         system.finish()
@@ -149,6 +152,8 @@ def driver_and_shards(rank, world, dev, model, H, W):
         out["ds_voxel_keys"] = bool(np.array_equal(vox_s[0], vox_1[0]))
         out["ds_voxel_values"] = bool(np.array_equal(vox_s[1], vox_1[1]) and np.array_equal(vox_s[2], vox_1[2]))
         out["ds_keyframes"] = len(sys_1.keyframes)
+        out["ds_relocalised"] = int(sys_1.stats["relocalised"])
+        out["ds_reloc_frames"] = int(sum(m == 2 for m in modes_1))
         out["ds_edges"] = int(sys_1.factor_graph.ii.numel())
         out["ds_voxels"] = int(len(vox_1[0]))
         out["ds_voxels_on_rank0"] = local_voxels

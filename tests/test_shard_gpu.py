@@ -35,7 +35,8 @@ def test_driver_and_shard_roles_are_bit_identical_to_one_rank(device, request):
     """The second half of the workers' run (tests/shard_worker.py::driver_and_shards): rank 0 runs the PRODUCT loop
     (SlamSystem) as the driver of a sharded session - pair inference + matching, global GN (one all-reduce per
     iteration), global TSDF voxels incl. the pose optimiser's owner-computes queries - while rank 1 serves
-    (mast3r_slam/shard.py); then rank 0 repeats the session alone.  Poses of every frame and keyframe, the factor graph,
+    (mast3r_slam/shard.py) - including a relocalisation (a frame from the other side of the room) - then rank 0 repeats the
+    session alone.  Poses of every frame and keyframe, the factor graph,
     the voxel table (keys AND values) and a set of TSDF normal equations must agree bit for bit."""
     job = getattr(request.config, "_shard_job", None)
     if job is None:
@@ -50,6 +51,7 @@ def test_driver_and_shard_roles_are_bit_identical_to_one_rank(device, request):
               "ds_voxel_keys", "ds_voxel_values"):
         assert res[k] is True, (k, res)
     assert res["ds_keyframes"] >= 4 and res["ds_edges"] >= res["ds_keyframes"] - 1 and res["ds_points_used"] > 20
+    assert res["ds_reloc_frames"] >= 1 and res["ds_relocalised"] >= 1          # the lost frame was relocalised - sharded, too
     # the voxels really were split: the driver's own table holds about half of them
     assert 0.3 * res["ds_voxels"] < res["ds_voxels_on_rank0"] < 0.7 * res["ds_voxels"], res
     ann = res["ds_announced"]          # add_factors, pointmaps, solve, fuse, maintain, refine, normal equations, voxels
