@@ -132,6 +132,14 @@ int mslam_gn_compact(const float* Xs, const float* Cs, const int64_t* idx_ii2jj,
                      const float* Q, int num_poses, int num_points, int num_edges, int edge_begin,
                      int edge_count, float C_thresh, float Q_thresh, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* compact() for edge ranges whose per-edge inputs do not lie in ONE array: the factor graph keeps the forward and the
+ * backward direction of its edges in two row-appendable buffers (global_opt.py:106-112 concatenates them for every
+ * solve: O(edges) copies of [E, HW] arrays per keyframe); a rank's accumulate range of `range_count` edges is compacted
+ * by one call per source array, each filling the slots [slot_begin, slot_begin + edge_count) of that range. */
+int mslam_gn_compact_at(const float* Xs, const float* Cs, const int64_t* idx_ii2jj, const uint8_t* valid_match,
+                        const float* Q, int num_poses, int num_points, int num_edges, int edge_begin, int edge_count,
+                        int slot_begin, int range_count, float C_thresh, float Q_thresh, void* workspace,
+                        size_t workspace_bytes, void* stream);
 int mslam_gn_accumulate(int kind, const float* Twc, const float* K, int num_poses, int num_points,
                         int num_edges, int edge_begin, int edge_count, float sigma_a, float sigma_b,
                         int height, int width, int pixel_border, float z_eps, float* Hs, float* gs,

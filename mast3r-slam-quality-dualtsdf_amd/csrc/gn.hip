@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gn_compact_kernel(
     const float* __restrict__ Xs, const float* __restrict__ Cs, const int* __restrict__ ii_edge,
     const int* __restrict__ jj_edge, const int64_t* __restrict__ idx_ii2jj,
     const uint8_t* __restrict__ valid_match, const float* __restrict__ Q, int num_points, int chunk_len,
-    float C_thresh, float Q_thresh, float* __restrict__ stream, int* __restrict__ counts, int S) {
+    float C_thresh, float Q_thresh, float* __restrict__ stream, int* __restrict__ counts, int S, int slot_begin) {
   // one-dimensional grid of S x edges workgroups (a y dimension would cap the edge count at 65 535)
   const int e = blockIdx.x / S, chunk = blockIdx.x - e * S;
   const int ix = ii_edge[e], jx = jj_edge[e];
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void gn_compact_kernel(
   const int64_t* __restrict__ idx_e = idx_ii2jj + (size_t)e * num_points;
   const uint8_t* __restrict__ vm_e = valid_match + (size_t)e * num_points;
   const float* __restrict__ Q_e = Q + (size_t)e * num_points;
-  float* __restrict__ slot = stream + ((size_t)e * S + chunk) * (size_t)chunk_len * kPlanes;
+  // the edge's slot of the stream: edges of one accumulate range may be compacted by several calls (slot_begin)
+  float* __restrict__ slot = stream + ((size_t)(slot_begin + e) * S + chunk) * (size_t)chunk_len * kPlanes;
   __shared__ int wave_cnt[4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int k_begin = chunk * chunk_len;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void gn_compact_kernel(
     base += total;
     __syncthreads();  // wave_cnt is rewritten by the next round
   }
-  if (threadIdx.x == 0) counts[e * S + chunk] = base;
+  if (threadIdx.x == 0) counts[(slot_begin + e) * S + chunk] = base;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1139,22 +1140,34 @@ extern "C" int mslam_gn_begin(const int64_t* ii, const int64_t* jj, int num_pose
   return check_hip(hipGetLastError(), "gn_begin launch");
 }
 
-extern "C" int mslam_gn_compact(const float* Xs, const float* Cs, const int64_t* idx_ii2jj,
-                                const uint8_t* valid_match, const float* Q, int num_poses, int num_points,
-                                int num_edges, int edge_begin, int edge_count, float C_thresh, float Q_thresh,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mslam_gn_compact_at(const float* Xs, const float* Cs, const int64_t* idx_ii2jj,
+                                   const uint8_t* valid_match, const float* Q, int num_poses, int num_points,
+                                   int num_edges, int edge_begin, int edge_count, int slot_begin, int range_count,
+                                   float C_thresh, float Q_thresh, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
   MSLAM_REQUIRE(num_poses >= 2 && num_points >= 1 && num_edges >= 1, "gn_compact: bad sizes");
   MSLAM_REQUIRE(edge_begin >= 0 && edge_count >= 0 && edge_begin + edge_count <= num_edges,
                 "gn_compact: edge range [%d,%d) outside [0,%d)", edge_begin, edge_begin + edge_count, num_edges);
+  MSLAM_REQUIRE(slot_begin >= 0 && slot_begin + edge_count <= range_count,
+                "gn_compact: slots [%d,%d) outside the accumulate range of %d edges", slot_begin,
+                slot_begin + edge_count, range_count);
   if (edge_count == 0) return MSLAM_OK;
   MSLAM_REQUIRE(Xs && Cs && idx_ii2jj && valid_match && Q, "gn_compact: null pointer");
-  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, edge_count);
+  GnWorkspace w = gn_carve(workspace, num_poses, num_edges, num_points, range_count);
   int rc = gn_check_ws(w.bytes, workspace, workspace_bytes, "gn_compact");
   if (rc) return rc;
   hipLaunchKernelGGL(gn_compact_kernel, dim3((unsigned)w.S * (unsigned)edge_count), dim3(256), 0, (hipStream_t)stream, Xs,
                      Cs, w.ii_edge + edge_begin, w.jj_edge + edge_begin, idx_ii2jj, valid_match, Q, num_points,
-                     w.chunk_len, C_thresh, Q_thresh, w.stream, w.counts, w.S);
+                     w.chunk_len, C_thresh, Q_thresh, w.stream, w.counts, w.S, slot_begin);
   return check_hip(hipGetLastError(), "gn_compact launch");
+}
+
+extern "C" int mslam_gn_compact(const float* Xs, const float* Cs, const int64_t* idx_ii2jj,
+                                const uint8_t* valid_match, const float* Q, int num_poses, int num_points,
+                                int num_edges, int edge_begin, int edge_count, float C_thresh, float Q_thresh,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  return mslam_gn_compact_at(Xs, Cs, idx_ii2jj, valid_match, Q, num_poses, num_points, num_edges, edge_begin,
+                             edge_count, 0, edge_count, C_thresh, Q_thresh, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mslam_gn_accumulate(int kind, const float* Twc, const float* K, int num_poses, int num_points,

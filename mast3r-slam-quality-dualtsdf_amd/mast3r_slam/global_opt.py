@@ -27,11 +27,13 @@ class FactorGraph:
         self.frames = frames
         self.device = device
         self.cfg = config["local_opt"]
-        z = lambda dt: torch.as_tensor([], dtype=dt, device=self.device)
-        self.ii, self.jj = z(torch.long), z(torch.long)
-        self.idx_ii2jj, self.idx_jj2ii = z(torch.long), z(torch.long)
-        self.valid_match_j, self.valid_match_i = z(torch.bool), z(torch.bool)
-        self.Q_ii2jj, self.Q_jj2ii = z(torch.float32), z(torch.float32)
+        # edge lists: row-appendable buffers (capacity doubling) instead of the reference's torch.cat per keyframe
+        # (global_opt.py:92-99), which copies every [E, HW] array - 0.7 GB each at 440 edges - whenever edges are added
+        # and again for every solve; the attributes below are views of the filled part
+        self._rows = {k: _Rows(dt, self.device) for k, dt in (
+            ("ii", torch.long), ("jj", torch.long), ("idx_ii2jj", torch.long), ("idx_jj2ii", torch.long),
+            ("valid_match_j", torch.bool), ("valid_match_i", torch.bool), ("Q_ii2jj", torch.float32),
+            ("Q_jj2ii", torch.float32))}
         self.window_size = self.cfg["window_size"]
         self.K = K
         self.last_unique_kf_idx = None
@@ -143,15 +145,28 @@ class FactorGraph:
         if invalid.any() and is_reloc:
             return False
         ok = ~invalid
-        self.ii = torch.cat([self.ii, ii_t[ok]])
-        self.jj = torch.cat([self.jj, jj_t[ok]])
-        self.idx_ii2jj = torch.cat([self.idx_ii2jj, idx_i2j[ok]])
-        self.idx_jj2ii = torch.cat([self.idx_jj2ii, idx_j2i[ok]])
-        self.valid_match_j = torch.cat([self.valid_match_j, valid_match_j[ok]])
-        self.valid_match_i = torch.cat([self.valid_match_i, valid_match_i[ok]])
-        self.Q_ii2jj = torch.cat([self.Q_ii2jj, Qj[ok]])
-        self.Q_jj2ii = torch.cat([self.Q_jj2ii, Qi[ok]])
+        for name, rows in (("ii", ii_t[ok]), ("jj", jj_t[ok]), ("idx_ii2jj", idx_i2j[ok]), ("idx_jj2ii", idx_j2i[ok]),
+                           ("valid_match_j", valid_match_j[ok]), ("valid_match_i", valid_match_i[ok]),
+                           ("Q_ii2jj", Qj[ok]), ("Q_jj2ii", Qi[ok])):
+            self._rows[name].append(rows)
         return ok.sum() > 0
+
+    ii = property(lambda self: self._rows["ii"].view)
+    jj = property(lambda self: self._rows["jj"].view)
+    idx_ii2jj = property(lambda self: self._rows["idx_ii2jj"].view)
+    idx_jj2ii = property(lambda self: self._rows["idx_jj2ii"].view)
+    valid_match_j = property(lambda self: self._rows["valid_match_j"].view)
+    valid_match_i = property(lambda self: self._rows["valid_match_i"].view)
+    Q_ii2jj = property(lambda self: self._rows["Q_ii2jj"].view)
+    Q_jj2ii = property(lambda self: self._rows["Q_jj2ii"].view)
+
+    def two_way_sources(self):
+        """The two-way edge set of prep_two_way_edges WITHOUT the concatenation of the big arrays: (ii, jj) of all 2E
+        directed edges (tiny) and the per-edge inputs as the two blocks they are stored in, in the reference's order
+        (forward edges, then backward): [(idx, valid, Q) of edges [0, E), (idx, valid, Q) of edges [E, 2E)]."""
+        ii = torch.cat((self.ii, self.jj), dim=0)
+        jj = torch.cat((self.jj, self.ii), dim=0)
+        return ii, jj, [(self.idx_ii2jj, self.valid_match_j, self.Q_ii2jj), (self.idx_jj2ii, self.valid_match_i, self.Q_jj2ii)]
 
     def get_unique_kf_idx(self):
         return torch.unique(torch.cat([self.ii, self.jj]), sorted=True)
@@ -190,11 +205,11 @@ class FactorGraph:
             img_size = self.frames[0].img.shape[-2:]
             Xs = constrain_points_to_ray(img_size, Xs, K)
             height, width = int(img_size[0]), int(img_size[1])
-        ii, jj, idx_ii2jj, valid_match, Q = self.prep_two_way_edges()
+        ii, jj, sources = self.two_way_sources()
         job = dict(kind=kind, pin=pin, unique_kf_idx=unique_kf_idx, unique_kf_idx_host=self.last_unique_kf_idx, K=K,
                    height=height, width=width,
                    pose_data=T_WCs.data[:, 0, :].contiguous(), Xs=Xs.contiguous(), Cs=Cs.contiguous(),
-                   edges=(ii, jj, idx_ii2jj, valid_match, Q))
+                   edges=(ii, jj, sources))
         if self._driver:     # which rows the shards do not hold in this state (store stamps; no stamps = all of them)
             stamp = getattr(self.frames, "stamp", None)
             dirty = []
@@ -209,21 +224,12 @@ class FactorGraph:
     def run_solve(self, job):
         c, kind, K = self.cfg, job["kind"], job["K"]
         pose_data, Xs, Cs = job["pose_data"], job["Xs"], job["Cs"]
-        ii, jj, idx_ii2jj, valid_match, Q = job["edges"]
+        ii, jj, sources = job["edges"]
         if self._driver:
             self._announce_solve(job)
-        if self.shard_edges and torch.distributed.is_available() and torch.distributed.is_initialized():
-            gauss_newton_sharded(kind, pose_data, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, c, job["height"],
-                                 job["width"], group=self.group)
-        elif kind == "rays":
-            mast3r_slam_backends.gauss_newton_rays(
-                pose_data, Xs, Cs, ii, jj, idx_ii2jj, valid_match, Q, c["sigma_ray"], c["sigma_dist"], c["C_conf"],
-                c["Q_conf"], c["max_iters"], c["delta_norm"])
-        else:
-            mast3r_slam_backends.gauss_newton_calib(
-                pose_data, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, job["height"], job["width"],
-                c["pixel_border"], c["depth_eps"], c["sigma_pixel"], c["sigma_depth"], c["C_conf"], c["Q_conf"],
-                c["max_iters"], c["delta_norm"])
+        sharded = self.shard_edges and torch.distributed.is_available() and torch.distributed.is_initialized()
+        gauss_newton_split(kind, pose_data, Xs, Cs, K, ii, jj, sources, c, job["height"], job["width"],
+                           group=self.group, sharded=sharded)
         job["Xs"] = job["Cs"] = job["edges"] = None     # the copies are no longer needed
 
     def commit_solve(self, job):
@@ -304,13 +310,24 @@ def edge_slice(E, rank, world):
 
 def gauss_newton_sharded(kind, Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q, cfg, height=0, width=0,
                          group=None):
-    """The GN loop of gn_kernels.cu:1181-1225 with the edge kernel sharded over ranks.  Per iteration:
-    local accumulate -> all_reduce(sum) of Hs and gs -> replicated solve + retraction.  Twc is updated
-    in place on every rank (identical bits).  Works on any backend torch.distributed offers for the
-    tensors' device ("nccl" = RCCL on ROCm)."""
-    import torch.distributed as dist
+    """The sharded GN loop on ONE array per per-edge input (the pybind functions' argument form)."""
+    return gauss_newton_split(kind, Twc, Xs, Cs, K, ii, jj, [(idx_ii2jj, valid_match, Q)], cfg, height, width,
+                              group=group, sharded=True)
 
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+def gauss_newton_split(kind, Twc, Xs, Cs, K, ii, jj, sources, cfg, height=0, width=0, group=None, sharded=False):
+    """The GN loop of gn_kernels.cu:1181-1225 on the split entry points.  `sources`: the per-edge inputs (idx, valid, Q) of
+    the E = len(ii) directed edges as a list of consecutive blocks (FactorGraph.two_way_sources: forward edges, backward
+    edges - no concatenation of the [E, HW] arrays).  sharded: the edge kernel runs on this rank's contiguous range of
+    the edges; per iteration: local accumulate -> all_reduce(sum) of Hs and gs -> replicated solve + retraction.  Twc is
+    updated in place on every rank (identical bits).  Works on any backend torch.distributed offers for the tensors'
+    device ("nccl" = RCCL on ROCm).  One rank / not sharded: the same calls without the all-reduce - bit-identical to
+    the fused mslam_gauss_newton_* entry points (same kernels in the same order)."""
+    rank, world = 0, 1
+    if sharded:
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
     P, HW, E = Xs.shape[0], Xs.shape[1], ii.shape[0]
     e0, cnt = edge_slice(E, rank, world)
     dev = Twc.device
@@ -319,17 +336,25 @@ def gauss_newton_sharded(kind, Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q
     blocks = torch.zeros(4 * E * 49 + 2 * E * 7, dtype=torch.float32, device=dev)  # one buffer, one all-reduce
     Hs, gs = blocks[: 4 * E * 49], blocks[4 * E * 49:]
     dx = torch.zeros((P - 1, 7), dtype=torch.float32, device=dev)
-    idx_l = idx_ii2jj[e0:e0 + cnt].contiguous()
-    vm_l = valid_match[e0:e0 + cnt].contiguous()
-    Q_l = Q[e0:e0 + cnt].contiguous()
     kid = {"rays": 0, "calib": 1, "points": 2}[kind]
     sa, sb = {"rays": (cfg["sigma_ray"], cfg["sigma_dist"]), "calib": (cfg["sigma_pixel"], cfg["sigma_depth"]),
               "points": (cfg.get("sigma_point", 0.05), 1.0)}[kind]
     _m.check(L.mslam_gn_begin(_m.ptr(ii), _m.ptr(jj), P, E, HW, _m.ptr(ws), ws.numel(), _m.stream_ptr()), "gn_begin")
-    # the pose-independent part (gather, confidence gates) once per call; the iterations stream the result
-    rc = L.mslam_gn_compact(_m.ptr(Xs), _m.ptr(Cs), _m.ptr(idx_l), _m.ptr(vm_l), _m.ptr(Q_l), P, HW, E, e0, cnt,
-                            float(cfg["C_conf"]), float(cfg["Q_conf"]), _m.ptr(ws), ws.numel(), _m.stream_ptr())
-    _m.check(rc, "gn_compact")
+    # the pose-independent part (gather, confidence gates) once per call; the iterations stream the result.  The range
+    # [e0, e0 + cnt) is compacted block by block of the sources it overlaps
+    keep, b0 = [], 0
+    for idx_b, vm_b, Q_b in sources:
+        nb = idx_b.shape[0]
+        lo, hi = max(e0, b0), min(e0 + cnt, b0 + nb)
+        if hi > lo:
+            idx_l, vm_l, Q_l = (t[lo - b0:hi - b0].contiguous() for t in (idx_b, vm_b, Q_b))   # row slices: views
+            keep.append((idx_l, vm_l, Q_l))
+            rc = L.mslam_gn_compact_at(_m.ptr(Xs), _m.ptr(Cs), _m.ptr(idx_l), _m.ptr(vm_l), _m.ptr(Q_l), P, HW, E, lo,
+                                       hi - lo, lo - e0, cnt, float(cfg["C_conf"]), float(cfg["Q_conf"]), _m.ptr(ws),
+                                       ws.numel(), _m.stream_ptr())
+            _m.check(rc, "gn_compact_at")
+        b0 += nb
+    assert b0 == E, (b0, E)
     for _ in range(int(cfg["max_iters"])):
         blocks.zero_()
         rc = L.mslam_gn_accumulate(
@@ -337,8 +362,37 @@ def gauss_newton_sharded(kind, Twc, Xs, Cs, K, ii, jj, idx_ii2jj, valid_match, Q
             int(height), int(width), int(cfg["pixel_border"]), float(cfg["depth_eps"]), _m.ptr(Hs), _m.ptr(gs),
             _m.ptr(ws), ws.numel(), _m.stream_ptr())
         _m.check(rc, "gn_accumulate")
-        dist.all_reduce(blocks, op=dist.ReduceOp.SUM, group=group)
+        if world > 1:
+            dist.all_reduce(blocks, op=dist.ReduceOp.SUM, group=group)
         rc = L.mslam_gn_solve_retract(_m.ptr(Hs), _m.ptr(gs), P, E, HW, _m.ptr(Twc), _m.ptr(dx),
                                       float(cfg["delta_norm"]), _m.ptr(ws), ws.numel(), _m.stream_ptr())
         _m.check(rc, "gn_solve_retract")
     return dx
+
+
+class _Rows:
+    """Row-appendable tensor: `view` = the rows appended so far (a view of a buffer that doubles when full)."""
+
+    def __init__(self, dtype, device):
+        self.dtype, self.device, self.buf, self.n = dtype, device, None, 0
+
+    def append(self, rows):
+        k = int(rows.shape[0])
+        if k == 0:
+            return
+        if self.buf is None or tuple(self.buf.shape[1:]) != tuple(rows.shape[1:]):
+            assert self.n == 0, "row shape changed"
+            self.buf = torch.empty((max(8, k),) + tuple(rows.shape[1:]), dtype=self.dtype, device=rows.device)
+        if self.n + k > self.buf.shape[0]:
+            grown = torch.empty((max(2 * self.buf.shape[0], self.n + k),) + tuple(self.buf.shape[1:]), dtype=self.dtype,
+                                device=self.buf.device)
+            grown[:self.n] = self.buf[:self.n]
+            self.buf = grown
+        self.buf[self.n:self.n + k] = rows
+        self.n += k
+
+    @property
+    def view(self):
+        if self.buf is None:
+            return torch.as_tensor([], dtype=self.dtype, device=self.device)
+        return self.buf[:self.n]

@@ -190,8 +190,8 @@ class BackendShard:
         pose_data = self.ch.bcast(torch.empty((P, 8), dtype=torch.float32, device=self.device))
         kind = ("rays", "calib", "points")[kind_id]
         K = torch.tensor(floats[:9], dtype=torch.float32, device=self.device).reshape(3, 3) if kind == "calib" else None
-        ii, jj, idx, vm, Q = fg.prep_two_way_edges()
+        ii, jj, sources = fg.two_way_sources()
         job = dict(kind=kind, pin=fg.cfg["pin"], K=K, height=height, width=width, pose_data=pose_data,
                    Xs=torch.stack([self.Xs[k] for k in ids]), Cs=torch.stack([self.Cs[k] for k in ids]),
-                   edges=(ii, jj, idx, vm, Q))
+                   edges=(ii, jj, sources))
         fg.run_solve(job)

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "mslam_gauss_newton_points": [_c_vp] * 8 + [_c_int] * 3 + [_c_float] * 3 + [_c_int, _c_float, _c_vp, _c_vp, _c_size, _c_vp],
     "mslam_gn_begin": [_c_vp] * 2 + [_c_int] * 3 + [_c_vp, _c_size, _c_vp],
     "mslam_gn_compact": [_c_vp] * 5 + [_c_int] * 5 + [_c_float] * 2 + [_c_vp, _c_size, _c_vp],
+    "mslam_gn_compact_at": [_c_vp] * 5 + [_c_int] * 7 + [_c_float] * 2 + [_c_vp, _c_size, _c_vp],
     "mslam_gn_accumulate": [_c_int] + [_c_vp] * 2 + [_c_int] * 5 + [_c_float] * 2 + [_c_int] * 3 + [_c_float] + [_c_vp] * 3 + [_c_size, _c_vp],
     "mslam_gn_solve_retract": [_c_vp] * 2 + [_c_int] * 3 + [_c_vp, _c_vp, _c_float, _c_vp, _c_size, _c_vp],
     "mslam_gn_status": [_c_vp] + [_c_int] * 3 + [_c_vp, _c_size, _c_vp],
