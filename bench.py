@@ -97,6 +97,8 @@ def parse():
     ap.add_argument("--pipeline-depth", type=int, default=0,
                     help="SlamSystem pipeline_depth: frames whose matching + pose solve are enqueued before the oldest verdict is "
                          "read (0 = the default: frame-at-a-time loop, which measures faster end to end: DESIGN.md)")
+    ap.add_argument("--encoder-priority", type=int, default=0,
+                    help="HIP stream priority of the look-ahead encoder stream (-1 = high)")
     ap.add_argument("--backend-priority", type=int, default=0,
                     help="HIP stream priority of the backend thread's stream (-1 = high)")
     ap.add_argument("--tracking-priority", type=int, default=0,
@@ -200,7 +202,7 @@ class Session:
                                  tsdf_global_cfg=tg, tsdf_refine_cfg=tr, quality_service=qs, decode_ahead=args.decode_ahead,
                                  backend="inline" if args.no_backend_thread else "thread", shard_channel=channel,
                                  pipeline=args.pipeline_depth > 0, pipeline_depth=max(1, args.pipeline_depth),
-                                 backend_priority=args.backend_priority)
+                                 backend_priority=args.backend_priority, encoder_priority=args.encoder_priority)
         # the stream: RGB frames rendered on the device, resident in HBM before the clock starts
         shp = torch.tensor([[H, W]])
         self.frames = []

@@ -86,7 +86,7 @@ class _BackendThread(threading.Thread):
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
                  backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0,
-                 shard_channel=None, pipeline=False, pipeline_depth=1, backend_priority=0):
+                 shard_channel=None, pipeline=False, pipeline_depth=1, backend_priority=0, encoder_priority=0):
         """`shard_channel` (mast3r_slam/shard.py): this process is the DRIVER rank of a session whose backend is sharded
         over the ranks of the channel's group - keyframe-pair inference + matching, the global GN (one all-reduce per
         iteration) and the global TSDF's voxels; the other ranks run BackendShard.serve()."""
@@ -125,7 +125,7 @@ class SlamSystem:
         self.mode = Mode.INIT
         self.last_T = None
         self.frame_group = max(1, int(frame_group))
-        self.enc_stream = torch.cuda.Stream(device=self.device) if self.frame_group > 1 else None
+        self.enc_stream = torch.cuda.Stream(device=self.device, priority=int(encoder_priority)) if self.frame_group > 1 else None
         self._enc_hi = 0
         self._kf_value, self._kf_slope = None, None      # keyframe-rule value of the last tracked frame, its decay per frame
         self._n_pending = 0                              # frames begun whose verdict is not read yet (pipelined run)
