@@ -91,6 +91,8 @@ def parse():
                     help="run the keyframe backend inline in the tracking loop (the reference's single_thread mode)")
     ap.add_argument("--frame-group", type=int, default=4,
                     help="frames whose network stages run in one batch call (SlamSystem frame groups)")
+    ap.add_argument("--encoder-group", type=int, default=0,
+                    help="frames per look-ahead encoder call (0 = the frame group)")
     ap.add_argument("--decode-ahead", type=int, default=0,
                     help="SlamSystem decode_ahead: issue the next group's pair decode on its own stream when at most this "
                          "many decoded frames are left (0: on the tracking stream when none is left)")
@@ -198,7 +200,7 @@ class Session:
             retriever = RetrievalDatabase(rw, torch.randn(65536, 1024, generator=g), device=dev)
         tg, tr = tsdf_cfgs(args)
         qs = SynchronousQualityService(device=dev, lookup_both=True) if tg is not None else None
-        self.system = SlamSystem(self.model, dev, retriever=retriever, frame_group=max(1, args.frame_group),
+        self.system = SlamSystem(self.model, dev, retriever=retriever, frame_group=max(1, args.frame_group), encoder_group=(args.encoder_group or None),
                                  tsdf_global_cfg=tg, tsdf_refine_cfg=tr, quality_service=qs, decode_ahead=args.decode_ahead,
                                  backend="inline" if args.no_backend_thread else "thread", shard_channel=channel,
                                  pipeline=args.pipeline_depth > 0, pipeline_depth=max(1, args.pipeline_depth),
@@ -590,8 +592,9 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
     barrier(world)
     kf0, e0 = ses.graph()
     st0 = dict(ses.system.stats)
+    st0["verdict_wait_s"] = ses.system.tracker.verdict_wait_s
     rows0 = (ses.model.enc_rows, ses.model.dec_rows)
-    M, N, K = dominant_shape(B)
+    M, N, K = dominant_shape(max(B, ses.system.encoder_group))   # the look-ahead encoder's batch
     mslam_hip.check(L.mslam_gemm_profile_begin(M, N, K, 8192), "gemm_profile_begin")
     prof = None
     if os.environ.get("BENCH_CPROFILE"):   # debug: where the frontend thread's host time goes
@@ -617,6 +620,7 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
                     "gemm_profile_end")
     kf1, e1 = ses.graph()
     st1 = dict(ses.system.stats)
+    st1["verdict_wait_s"] = ses.system.tracker.verdict_wait_s
     iso_us = isolated_dominant_us(L, mslam_hip, M, N, K, dev) if not args.no_network else 0.0
     hbm = hbm_kernel_probes(ses, dev)
     enc_rows, dec_rows = ses.model.enc_rows - rows0[0], ses.model.dec_rows - rows0[1]
@@ -664,7 +668,7 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
                        "weights": "random-init ViT-L/12+12 MASt3R architecture (no checkpoint offline); geometry from the "
                                   "procedural room stand-in, rendered on the device inside the timed region",
                        "backend": "inline" if args.no_backend_thread else "own host thread + stream (as the reference's backend process)",
-                       "frame_group": B, "camera_path_stride": args.stride, "match_frac_thresh": args.kf_thresh,
+                       "frame_group": B, "encoder_group": ses.system.encoder_group, "camera_path_stride": args.stride, "match_frac_thresh": args.kf_thresh,
                        "stats": {"keyframes": kf1, "new_keyframes": new_kf, "new_edges": new_e,
                                  "decoded_rows_tracking": st1["decoded_rows"] - st0["decoded_rows"],
                                  "void_rows": st1["void_rows"] - st0["void_rows"],

@@ -279,6 +279,28 @@ int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, const float* 
                      int first_iter, int max_iters, float rel_error, float delta_norm, void* status_out, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* The tensor expressions of FrameTracker.track around the pose loop (mast3r_slam/tracker.py:44-75: Qk, the validity
+ * masks, match_frac; :147-177: the keyframe rule's two fractions and the keyframe's pointmap fused with the frame's view
+ * of it, frame.py:41-105 'weighted_pointmap'; lietorch inv / mul / act at tracker.py:150,232) as three launches.  Each
+ * value is produced by the same single IEEE operations, in the same order, as the op-by-op tensor form.
+ * mslam_track_prepare: for keyframe pixel k with j = idx_f2k[k]:
+ *   Qk[k] = sqrt(Qff[j] * Qkf[k]);  Cf = Cf_sum[j] * inv_nf;  Ck_avg[k] = Ck_sum[k] * inv_nk   (C / N of a Frame)
+ *   valid_opt[k] = valid_match[k] & Cf > C_conf & Ck > C_conf & Qk > Q_conf;  valid_kf[k] = valid_match[k] & Qk > Q_conf
+ *   T_rel = T_WCk^-1 * T_WCf (f32[8] each, unit quaternions as lietorch keeps them)
+ *   workspace <- {i32 #valid_opt, i32 #valid_kf, i32 #distinct idx_f2k[k] with valid_match[k]} + a bitmap.
+ * mslam_track_verdict: verdict6 <- {#valid_opt / n, iterations, chol_fail, #valid_kf / n, #distinct / n, done} with the
+ *   solver status of mslam_track_pose (status_out) - the six scalars FrameTracker reads per frame.
+ * mslam_track_fuse: T_WCf = T_WCk * T_rel;  X_new = ((C X_canon) + (Ckf (T_rel . Xkf))) / (C + Ckf);  C_new = C + Ckf. */
+size_t mslam_track_prepare_workspace_bytes(int n_points);
+int mslam_track_prepare(const int64_t* idx_f2k, const uint8_t* valid_match, const float* Qff, const float* Qkf,
+                        const float* Cf_sum, float inv_nf, const float* Ck_sum, float inv_nk, float C_conf, float Q_conf,
+                        int n_points, const float* T_WCk, const float* T_WCf, float* Qk, float* Ck_avg,
+                        uint8_t* valid_opt, uint8_t* valid_kf, float* T_rel, void* workspace, size_t workspace_bytes,
+                        void* stream);
+int mslam_track_verdict(const void* prepare_workspace, const void* status, int n_points, float* verdict6, void* stream);
+int mslam_track_fuse(const float* T_WCk, const float* T_rel, const float* Xkf, const float* Ckf, const float* X_canon,
+                     const float* C, int n_points, float* T_WCf, float* X_new, float* C_new, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Building blocks of the MASt3R forward, exported for kernel-level parity tests and roofline
  * measurement (they have no counterpart in the reference's API: it calls cuBLAS/cuDNN through

@@ -25,7 +25,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 constexpr int BK = 64;
 // Measurement builds only (tools/probes/build_gemm_ablate.sh): 1 = no DMA behind the prologue (MFMA + fragment reads +
-// barriers), 2 = no MFMA (DMA + waits + barriers + fragment reads), 3 = no fragment reads (MFMA on stale registers).
+// barriers), 2 = no MFMA (DMA + waits + barriers + fragment reads), 3 = no fragment reads (MFMA on stale registers),
+// 4 = the same FLOP count through v_mfma_f32_16x16x32_bf16 (two per 32x32x16 instruction, quarter accumulators): a clock
+// / issue probe for the other MFMA shape, not a GEMM.
 #ifndef MSLAM_GEMM_ABLATE
 #define MSLAM_GEMM_ABLATE 0
 #endif
@@ -239,6 +241,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
     for (int ni = 0; ni < NI; ni++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.0f;
+#if MSLAM_GEMM_ABLATE == 4
+  typedef __attribute__((ext_vector_type(4))) float f32x4q;
+  f32x4q acc4[MI][NI][4];
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc4[mi][ni][r] = f32x4q{0.0f, 0.0f, 0.0f, 0.0f};
+#endif
 
   // fragment addressing: row lr of the wave's 32-row slab, K half h; slot = (2*ks + h) ^ ((lr >> 1) & 7)
   const int lr = lane & 31, kh = (lane >> 5) ^ ((lr >> 1) & 7);
@@ -281,6 +293,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
           for (int ni = 0; ni < NI; ni++) {
             if (MSLAM_GEMM_ABLATE == 2) {   // keep the fragments alive without the matrix instruction
               asm volatile("" ::"v"(af[k][mi]), "v"(bfr[k][ni]));
+#if MSLAM_GEMM_ABLATE == 4
+            } else if (true) {
+              acc4[mi][ni][2 * (k & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][mi], bfr[k][ni], acc4[mi][ni][2 * (k & 1)], 0, 0, 0);
+              acc4[mi][ni][2 * (k & 1) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][mi], bfr[k][ni], acc4[mi][ni][2 * (k & 1) + 1], 0, 0, 0);
+#endif
             } else {
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][mi], bfr[k][ni], acc[mi][ni], 0, 0, 0);
             }
@@ -319,6 +336,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmArgs g) {
     st = (st + 1 == S) ? 0 : st + 1;
   }
 
+#if MSLAM_GEMM_ABLATE == 4
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[mi][ni][r] = acc4[mi][ni][r >> 2][r & 3];
+#endif
   // ---- epilogue ------------------------------------------------------------------------------
   // Every accumulator index below is a compile-time constant (static_for): a runtime-indexed
   // ext_vector array would be demoted to scratch memory and spilled inside the K loop.

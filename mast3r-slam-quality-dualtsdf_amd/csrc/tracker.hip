@@ -195,6 +195,90 @@ __global__ void track_init_kernel(TrackState* st) {
   st->last_delta_norm = 0.0f; st->pad0 = st->pad1 = 0.0f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The tensor glue around the pose loop as three launches (FrameTracker.track: tracker.py:44-75 masks and
+// fractions, :147-177 the keyframe rule's inputs and the fusion of the keyframe's pointmap).  Every value is
+// computed with the single IEEE operations the frontend's tensor expressions use (no contraction in this TU),
+// in the same order, so the fused form is bit-identical to the op-by-op form it replaces.
+// ---------------------------------------------------------------------------------------------
+struct PrepCounts {
+  int n_opt;      // valid_match & Cf > C_conf & Ck > C_conf & Qk > Q_conf
+  int n_kf;       // valid_match & Qk > Q_conf
+  int n_unique;   // distinct idx_f2k[k] among the pixels with valid_match
+  int pad;
+};
+
+__global__ __launch_bounds__(256) void track_prep_kernel(
+    const int64_t* __restrict__ idx, const uint8_t* __restrict__ vmatch, const float* __restrict__ Qff,
+    const float* __restrict__ Qkf, const float* __restrict__ Cf_sum, float inv_nf, const float* __restrict__ Ck_sum,
+    float inv_nk, float C_conf, float Q_conf, int n, const float* __restrict__ T_WCk, const float* __restrict__ T_WCf,
+    float* __restrict__ Qk, float* __restrict__ Ck_avg, uint8_t* __restrict__ valid_opt, uint8_t* __restrict__ valid_kf,
+    float* __restrict__ T_rel, PrepCounts* __restrict__ counts, unsigned* __restrict__ bitmap) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k == 0) {   // T_CkCf = T_WCk^-1 * T_WCf, each factor a lietorch object (unit quaternion)
+    const Sim3f Ti = sim3_unit(sim3_inv(sim3_load(T_WCk)));
+    sim3_store(T_rel, sim3_unit(sim3_mul(Ti, sim3_load(T_WCf))));
+  }
+  bool opt = false, kf = false, first = false;
+  if (k < n) {
+    const long long j = idx[k];
+    const bool vm = vmatch[k] != 0;
+    const float q = sqrtf(Qff[j] * Qkf[k]);
+    const float cf = Cf_sum[j] * inv_nf;      // tensor / python int on the device = multiply by the fp32 reciprocal
+    const float ck = Ck_sum[k] * inv_nk;
+    const bool vq = q > Q_conf;
+    opt = vm && (cf > C_conf) && (ck > C_conf) && vq;
+    kf = vm && vq;
+    Qk[k] = q;
+    Ck_avg[k] = ck;
+    valid_opt[k] = opt ? 1 : 0;
+    valid_kf[k] = kf ? 1 : 0;
+    if (vm) {
+      const unsigned bit = 1u << (j & 31);
+      first = (atomicOr(&bitmap[j >> 5], bit) & bit) == 0;
+    }
+  }
+  const int c_opt = __popcll(__ballot(opt)), c_kf = __popcll(__ballot(kf)), c_un = __popcll(__ballot(first));
+  if ((threadIdx.x & 63) == 0) {
+    if (c_opt) atomicAdd(&counts->n_opt, c_opt);
+    if (c_kf) atomicAdd(&counts->n_kf, c_kf);
+    if (c_un) atomicAdd(&counts->n_unique, c_un);
+  }
+}
+
+// {match_frac, iterations, chol_fail, kf_frac, unique_frac, done}: a mean of 0/1 values is count * (1 / n) in fp32
+__global__ void track_verdict_kernel(const PrepCounts* __restrict__ counts, const int* __restrict__ status, int n,
+                                     float* __restrict__ out) {
+  const float inv_n = 1.0f / (float)n;
+  out[0] = (float)counts->n_opt * inv_n;
+  out[1] = (float)status[1];
+  out[2] = (float)status[2];
+  out[3] = (float)counts->n_kf * inv_n;
+  out[4] = (float)counts->n_unique * inv_n;
+  out[5] = (float)status[0];
+}
+
+// The effects of a tracked frame (tracker.py:147-168, frame.py:41-105 'weighted_pointmap'): T_WCf = T_WCk * T_CkCf,
+// the keyframe's pointmap fused with the frame's view of it: X' = ((C X) + (Ckf Xkk)) / (C + Ckf), C' = C + Ckf with
+// Xkk = T_CkCf . Xkf
+__global__ __launch_bounds__(256) void track_fuse_kernel(const float* __restrict__ T_WCk, const float* __restrict__ T_rel,
+                                                         const float* __restrict__ Xkf, const float* __restrict__ Ckf,
+                                                         const float* __restrict__ Xc, const float* __restrict__ Cc, int n,
+                                                         float* __restrict__ T_WCf, float* __restrict__ Xn,
+                                                         float* __restrict__ Cn) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const Sim3f Tr = sim3_load(T_rel);
+  if (k == 0) sim3_store(T_WCf, sim3_unit(sim3_mul(sim3_load(T_WCk), Tr)));
+  if (k >= n) return;
+  const float x[3] = {Xkf[(size_t)k * 3], Xkf[(size_t)k * 3 + 1], Xkf[(size_t)k * 3 + 2]};
+  float y[3];
+  sim3_act(Tr, x, y);
+  const float c = Cc[k], cn = Ckf[k], den = c + cn;
+#pragma unroll
+  for (int d = 0; d < 3; d++) Xn[(size_t)k * 3 + d] = ((c * Xc[(size_t)k * 3 + d]) + (cn * y[d])) / den;
+  Cn[k] = den;
+}
+
 }  // namespace mslam
 
 using namespace mslam;
@@ -242,5 +326,48 @@ extern "C" int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, co
   MSLAM_LAUNCH_CHECK("track_pose");
   if (status_out)
     return check_hip(hipMemcpyAsync(status_out, st, sizeof(TrackState), hipMemcpyDeviceToDevice, s), "track status");
+  return MSLAM_OK;
+}
+
+extern "C" size_t mslam_track_prepare_workspace_bytes(int n_points) {
+  return 256 + 4 * (size_t)((n_points + 31) / 32);
+}
+
+extern "C" int mslam_track_prepare(const int64_t* idx_f2k, const uint8_t* valid_match, const float* Qff,
+                                   const float* Qkf, const float* Cf_sum, float inv_nf, const float* Ck_sum,
+                                   float inv_nk, float C_conf, float Q_conf, int n_points, const float* T_WCk,
+                                   const float* T_WCf, float* Qk, float* Ck_avg, uint8_t* valid_opt, uint8_t* valid_kf,
+                                   float* T_rel, void* workspace, size_t workspace_bytes, void* stream) {
+  MSLAM_REQUIRE(n_points > 0, "track_prepare: bad sizes");
+  MSLAM_REQUIRE(idx_f2k && valid_match && Qff && Qkf && Cf_sum && Ck_sum && T_WCk && T_WCf && Qk && Ck_avg && valid_opt &&
+                    valid_kf && T_rel && workspace, "track_prepare: null pointer");
+  MSLAM_REQUIRE(workspace_bytes >= mslam_track_prepare_workspace_bytes(n_points), "track_prepare: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = check_hip(hipMemsetAsync(workspace, 0, mslam_track_prepare_workspace_bytes(n_points), s), "track_prepare: memset");
+  if (rc) return rc;
+  hipLaunchKernelGGL(track_prep_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, idx_f2k, valid_match, Qff, Qkf,
+                     Cf_sum, inv_nf, Ck_sum, inv_nk, C_conf, Q_conf, n_points, T_WCk, T_WCf, Qk, Ck_avg, valid_opt,
+                     valid_kf, T_rel, (PrepCounts*)workspace, (unsigned*)((char*)workspace + 256));
+  MSLAM_LAUNCH_CHECK("track_prepare");
+  return MSLAM_OK;
+}
+
+extern "C" int mslam_track_verdict(const void* prepare_workspace, const void* status, int n_points, float* verdict6,
+                                   void* stream) {
+  MSLAM_REQUIRE(prepare_workspace && status && verdict6 && n_points > 0, "track_verdict: bad arguments");
+  hipLaunchKernelGGL(track_verdict_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const PrepCounts*)prepare_workspace,
+                     (const int*)status, n_points, verdict6);
+  MSLAM_LAUNCH_CHECK("track_verdict");
+  return MSLAM_OK;
+}
+
+extern "C" int mslam_track_fuse(const float* T_WCk, const float* T_rel, const float* Xkf, const float* Ckf,
+                                const float* X_canon, const float* C, int n_points, float* T_WCf, float* X_new,
+                                float* C_new, void* stream) {
+  MSLAM_REQUIRE(n_points > 0, "track_fuse: bad sizes");
+  MSLAM_REQUIRE(T_WCk && T_rel && Xkf && Ckf && X_canon && C && T_WCf && X_new && C_new, "track_fuse: null pointer");
+  hipLaunchKernelGGL(track_fuse_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)stream, T_WCk, T_rel, Xkf,
+                     Ckf, X_canon, C, n_points, T_WCf, X_new, C_new);
+  MSLAM_LAUNCH_CHECK("track_fuse");
   return MSLAM_OK;
 }

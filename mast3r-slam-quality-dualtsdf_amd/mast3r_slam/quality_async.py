@@ -18,7 +18,15 @@ from mast3r_slam.quality_core import compute_batch
 
 
 def _prep_job(j, dev):
-    """quality_async.py:12-46."""
+    """quality_async.py:12-46.  A job may carry its residual map as a deferred expression (`lazy`, FrameTracker): it is
+    evaluated here, i.e. only for the jobs that are actually computed."""
+    if "lazy" in j:
+        j = dict(j)
+        if torch.cuda.is_available():
+            for t in j.get("keep", ()):          # inputs allocated on the tracking stream, read on this one
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(torch.cuda.current_stream(t.device))
+        j.update(j.pop("lazy")())
     out = {"kf_id": int(j["kf_id"]), "frame_id": int(j.get("frame_id", j["kf_id"])), "H": int(j["H"]), "W": int(j["W"]),
            "t_norm": torch.as_tensor(j["t_norm"], device=dev, dtype=torch.float32),
            "theta": torch.as_tensor(j["theta"], device=dev, dtype=torch.float32)}

@@ -85,6 +85,7 @@ class _BackendThread(threading.Thread):
 
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
+                 encoder_group=None,
                  backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0,
                  shard_channel=None, pipeline=False, pipeline_depth=1, backend_priority=0, encoder_priority=0):
         """`shard_channel` (mast3r_slam/shard.py): this process is the DRIVER rank of a session whose backend is sharded
@@ -125,6 +126,9 @@ class SlamSystem:
         self.mode = Mode.INIT
         self.last_T = None
         self.frame_group = max(1, int(frame_group))
+        # the look-ahead encoder does not depend on any decision of the loop (every frame is encoded exactly once), so
+        # its batch may be larger than the speculative decode group: nothing is ever encoded in vain
+        self.encoder_group = self.frame_group if encoder_group is None else max(1, int(encoder_group))
         self.enc_stream = torch.cuda.Stream(device=self.device, priority=int(encoder_priority)) if self.frame_group > 1 else None
         self._enc_hi = 0
         self._kf_value, self._kf_slope = None, None      # keyframe-rule value of the last tracked frame, its decay per frame
@@ -187,9 +191,7 @@ class SlamSystem:
             if pend:
                 k, h = pend.pop(0)
                 with self._critical("main"):
-                    t_wait = time.perf_counter()
                     self.tracker.track_resolve(h)
-                    self.stats["verdict_wait_s"] = self.stats.get("verdict_wait_s", 0.0) + time.perf_counter() - t_wait
                     clean = h.kind == "ok" and not h.new_kf and not h.replayed
                     if pend and not clean:              # the premise of everything begun behind it failed: undo, newest first
                         for _, hh in reversed(pend):
@@ -420,9 +422,10 @@ class SlamSystem:
 
     def _look_ahead(self, frames, i, stop=None):
         B, n = self.frame_group, (len(frames) if stop is None else stop)
+        EB = max(B, self.encoder_group)
         main = torch.cuda.current_stream(self.device)
-        while self._enc_hi < min(n, i + 2 * B):          # encoder: groups of B, up to two groups ahead of frame i
-            grp = [frames[k] for k in range(self._enc_hi, min(n, self._enc_hi + B))]
+        while self._enc_hi < min(n, i + EB + B):         # encoder: groups of EB, at least one decode group ahead of frame i
+            grp = [frames[k] for k in range(self._enc_hi, min(n, self._enc_hi + EB))]
             self.enc_stream.wait_stream(main)            # the images were produced on the caller's stream
             with torch.cuda.stream(self.enc_stream):
                 mu.encode_frames(self.model, grp)

@@ -3,6 +3,7 @@ values.  Inference + matching + the whole <=50-iteration Sim3 Gauss-Newton run i
 quality-service submission (tracker.py:94-145) happens when a `quality_service` is attached (main.py:246), with
 device tensors in the job instead of numpy copies."""
 import copy
+import time
 
 import numpy as np
 import torch
@@ -17,7 +18,7 @@ from mast3r_slam.mast3r_utils import mast3r_match_asymmetric
 class _Pending:
     """One tracked frame between track_begin (everything enqueued, effects applied optimistically) and track_finish."""
     __slots__ = ("frame", "init_T", "prev_idx", "prev_shadow", "stash", "base", "shadow", "slot", "job", "verdict",
-                 "event", "quality", "T_WCf", "T_CkCf", "Xkf", "Ckf", "Qkf", "Qff", "status", "pack_args", "replayed",
+                 "event", "quality", "T_WCf", "T_CkCf", "T_WCk", "Xkf", "Ckf", "Qkf", "Qff", "status", "n_points", "replayed",
                  "kind", "vals", "new_kf")
 
 
@@ -31,11 +32,12 @@ class FrameTracker:
         self.device = device
         self.reset_idx_f2k()
         self.N_SLOTS = 4           # solver loop states in flight: the frame being resolved + up to 3 begun behind it
-        self._slots = [dict(ws=None, status=None, host=None) for _ in range(self.N_SLOTS)]
+        self._slots = [dict(ws=None, status=None, host=None, prep=None) for _ in range(self.N_SLOTS)]
         self._slot = 0
         self._shadow = None        # fused state of the current keyframe that has not been written to the store yet
         self.quality_service = None
         self.last_kf_value = None
+        self.verdict_wait_s = 0.0  # host time spent waiting for verdicts (the one blocking read per tracked frame)
 
     def reset_idx_f2k(self):
         self.idx_f2k = None
@@ -64,57 +66,85 @@ class FrameTracker:
         self.idx_f2k = idx_f2k.clone()
         idx_f2k = idx_f2k[0]
         valid_match_k = valid_match_k[0]
-        Qk = torch.sqrt(Qff[idx_f2k] * Qkf)
         frame.update_pointmap(Xff, Cff)
 
         use_calib = config["use_calib"]
         img_size = frame.img.shape[-2:]
         K = keyframe.K if use_calib else None
         T_WCk = stored.T_WC            # poses live in the store (the backend's write-backs land there)
-        Xf, Xk, T_WCf, _, Cf, Ck, meas_k, valid_meas_k = self.get_points_poses(
-            frame, keyframe, idx_f2k, img_size, use_calib, K)
-
-        valid_Cf = Cf > self.cfg["C_conf"]
-        valid_Ck = Ck > self.cfg["C_conf"]
-        valid_Q = Qk > self.cfg["Q_conf"]
-        valid_opt = valid_match_k & valid_Cf & valid_Ck & valid_Q
-        valid_kf = valid_match_k & valid_Q
+        Xf, Xk = frame.X_canon, keyframe.X_canon       # get_points_poses (tracker.py:181-206) without its tensor ops:
+        if use_calib:                                  # the gathers, C / N and the masks below happen in ONE launch
+            Xf = constrain_points_to_ray(img_size, Xf[None], K).squeeze(0)
+            Xk = constrain_points_to_ray(img_size, Xk[None], K).squeeze(0)
+        self._idx = idx_f2k
 
         # ONE host read per tracked frame: the reference branches on the host four times (match fraction :72-75, solver
         # failure :91-93, the two fractions of the keyframe decision :170-177).  Here the solver is enqueued
         # unconditionally (its result is dropped when the match-fraction gate fails) and the six scalars come back in
-        # one small copy into pinned memory behind an event; the unique count is a scatter instead of torch.unique.
-        match_frac = valid_opt.float().mean()
+        # one small copy into pinned memory behind an event.  Qk, the masks (tracker.py:61-70), their fractions, the
+        # unique-match count and T_CkCf = T_WCk^-1 * T_WCf are one launch (mslam_track_prepare) instead of ~30 tensor
+        # ops with a launch bubble behind each.
         h.slot = self._slot
         self._slot = (self._slot + 1) % self.N_SLOTS
         self._cur = h
-        if not use_calib:
-            T_WCf, T_CkCf, status = self._run_async(False, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, None, None, chunked=True)
-        else:
-            T_WCf, T_CkCf, status = self._run_async(True, Xf, Xk, T_WCf, T_WCk, Qk, valid_opt, K, img_size, chunked=True)
-        h.job = getattr(self, "_job", None)
-        hits = torch.zeros(valid_kf.numel(), dtype=torch.int32, device=idx_f2k.device)
-        hits.index_add_(0, idx_f2k, valid_match_k[:, 0].to(torch.int32))
-        h.pack_args = (match_frac, valid_kf.float().mean(), (hits > 0).float().mean())
+        Qk, Ck, valid_opt, valid_kf, T_rel = self._prepare(h, frame, keyframe, idx_f2k, valid_match_k, Qff, Qkf,
+                                                           T_WCk, frame.T_WC)
+        T_WCf, T_CkCf, status = self._run_async(use_calib, Xf, Xk, None, T_WCk, Qk, valid_opt, K if use_calib else None,
+                                                img_size if use_calib else None, chunked=True, T_rel=T_rel, pose=False)
+        h.job, h.T_WCk = getattr(self, "_job", None), T_WCk
         h.status = status
         self._post_verdict(h)
         h.quality = None
         if self.quality_service is not None and not use_calib:   # tracker.py:94-145 (ray-distance residual form)
-            Xf_g = Xf[idx_f2k]                                    # the reference's Xf is the gathered one (:181-206)
-            rd_k = point_to_ray_dist(Xk, jacobian=False)
-            h.quality = dict(Xf_g=Xf_g, rd_k=rd_k, valid_kf=valid_kf.view(-1), Ck=Ck.view(-1), Qk=Qk.view(-1),
+            # the residual map is needed only if this job is still the keyframe's newest one when the service computes
+            # (a newer job replaces a queued one): the inputs ride along, the tensor expressions run in the service
+            h.quality = dict(Xf=Xf, idx=idx_f2k, Xk=Xk, valid_kf=valid_kf.view(-1), Ck=Ck.view(-1), Qk=Qk.view(-1),
                              kf_id=int(len(self.keyframes) - 1), frame_id=int(keyframe.frame_id), H=int(img_size[0]),
                              W=int(img_size[1]))
         h.base, h.Xkf, h.Ckf, h.Qkf, h.Qff = keyframe, Xkf, Ckf, Qkf, Qff
         self._apply(h, T_WCf, T_CkCf)
         return h
 
+    def _prepare(self, h, frame, keyframe, idx_f2k, valid_match_k, Qff, Qkf, T_WCk, T_WCf):
+        """tracker.py:61-70 + the fractions of :72-75 / :170-177 + T_CkCf -> (Qk, Ck, valid_opt, valid_kf, T_rel);
+        the three counts stay on the device (slot workspace) for _post_verdict."""
+        n = int(keyframe.X_canon.shape[0])
+        dev = idx_f2k.device
+        L = _m.lib()
+        sl = self._slots[h.slot]
+        need = L.mslam_track_prepare_workspace_bytes(n)
+        if sl.get("prep") is None or sl["prep"].numel() < need:
+            sl["prep"] = torch.empty(need, dtype=torch.uint8, device=dev)
+        Qk = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        Ck = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        valid_opt = torch.empty((n, 1), dtype=torch.bool, device=dev)
+        valid_kf = torch.empty((n, 1), dtype=torch.bool, device=dev)
+        T_rel = torch.empty(8, dtype=torch.float32, device=dev)
+        idx_c, vm_c = idx_f2k.contiguous(), valid_match_k.contiguous()
+        Qff_c, Qkf_c = Qff.contiguous(), Qkf.contiguous()
+        Cf_c, Ck_c = frame.C.contiguous(), keyframe.C.contiguous()
+        Tk_c, Tf_c = T_WCk.data.reshape(8).contiguous(), T_WCf.data.reshape(8).contiguous()
+        _m.require_dtype(idx_c, torch.int64, "idx_f2k")
+        _m.require_dtype(vm_c, torch.bool, "valid_match_k")
+        # Frame.get_average_conf is C / N with N a python int: on the device that is C * (1 / N) in fp32
+        inv_nf = float(np.float32(1.0) / np.float32(frame.N))
+        inv_nk = float(np.float32(1.0) / np.float32(keyframe.N))
+        rc = L.mslam_track_prepare(_m.ptr(idx_c), _m.ptr(vm_c), _m.ptr(Qff_c), _m.ptr(Qkf_c), _m.ptr(Cf_c), inv_nf,
+                                   _m.ptr(Ck_c), inv_nk, float(self.cfg["C_conf"]), float(self.cfg["Q_conf"]), n,
+                                   _m.ptr(Tk_c), _m.ptr(Tf_c), _m.ptr(Qk), _m.ptr(Ck), _m.ptr(valid_opt),
+                                   _m.ptr(valid_kf), _m.ptr(T_rel), _m.ptr(sl["prep"]), sl["prep"].numel(),
+                                   _m.stream_ptr())
+        _m.check(rc, "track_prepare")
+        h.n_points = n
+        return Qk, Ck, valid_opt, valid_kf, T_rel
+
     def _post_verdict(self, h):
         """The six scalars of the verdict -> pinned host memory, asynchronously, with an event behind the copy."""
-        st = h.status
-        mf, kf_frac, uniq = h.pack_args
-        dev = torch.stack((mf, st[1].float(), st[2].float(), kf_frac, uniq, st[0].float()))
         sl = self._slots[h.slot]
+        dev = torch.empty(6, dtype=torch.float32, device=h.status.device)
+        rc = _m.lib().mslam_track_verdict(_m.ptr(sl["prep"]), _m.ptr(h.status), int(h.n_points), _m.ptr(dev),
+                                          _m.stream_ptr())
+        _m.check(rc, "track_verdict")
         if sl["host"] is None:
             sl["host"] = torch.empty(6, dtype=torch.float32).pin_memory()
         sl["host"].copy_(dev, non_blocking=True)
@@ -124,15 +154,38 @@ class FrameTracker:
 
     def _apply(self, h, T_WCf, T_CkCf):
         """Optimistic effects of a tracked frame (tracker.py:147-168): the frame's pose, the keyframe's pointmap fused
-        with the frame's view of it - into a shadow copy, the store is written by track_finish."""
-        h.T_WCf, h.T_CkCf = T_WCf, T_CkCf
-        h.frame.T_WC = T_WCf
-        Xkk = T_CkCf.act(h.Xkf)
-        shadow = copy.copy(h.base)
+        with the frame's view of it - into a shadow copy, the store is written by track_finish.  In the default
+        filtering mode ('weighted_pointmap', frame.py:72-75) pose product, act and fusion are one launch."""
+        h.T_CkCf = T_CkCf
+        base = h.base
+        shadow = copy.copy(base)
         shadow._in_store, shadow._replaced_by = False, None      # (the copy inherits the marks of a committed base)
-        if config["tracking"]["filtering_mode"] in self.IN_PLACE_MODES:
-            shadow.X_canon, shadow.C = shadow.X_canon.clone(), shadow.C.clone()
-        shadow.update_pointmap(Xkk, h.Ckf)
+        T_WCk = h.T_WCk
+        if config["tracking"]["filtering_mode"] == "weighted_pointmap" and base.N > 0:
+            n = int(base.X_canon.shape[0])
+            dev = base.X_canon.device
+            T_out = torch.empty((1, 8), dtype=torch.float32, device=dev)
+            X_new, C_new = torch.empty_like(base.X_canon), torch.empty_like(base.C)
+            Tk_c, Tr_c = T_WCk.data.reshape(8).contiguous(), T_CkCf.data.reshape(8).contiguous()
+            Xkf_c, Ckf_c = h.Xkf.contiguous(), h.Ckf.contiguous()
+            Xc_c, Cc_c = base.X_canon.contiguous(), base.C.contiguous()
+            assert X_new.is_contiguous() and C_new.is_contiguous()
+            rc = _m.lib().mslam_track_fuse(_m.ptr(Tk_c), _m.ptr(Tr_c), _m.ptr(Xkf_c), _m.ptr(Ckf_c), _m.ptr(Xc_c),
+                                           _m.ptr(Cc_c), n, _m.ptr(T_out), _m.ptr(X_new), _m.ptr(C_new), _m.stream_ptr())
+            _m.check(rc, "track_fuse")
+            if T_WCf is None:                  # (a caller that solved the pose itself passes it)
+                T_WCf = Sim3(T_out)
+            shadow.X_canon, shadow.C = X_new, C_new
+            shadow.N, shadow.N_updates = base.N + 1, base.N_updates + 1
+        else:
+            if T_WCf is None:
+                T_WCf = T_WCk * T_CkCf
+            Xkk = T_CkCf.act(h.Xkf)
+            if config["tracking"]["filtering_mode"] in self.IN_PLACE_MODES:
+                shadow.X_canon, shadow.C = shadow.X_canon.clone(), shadow.C.clone()
+            shadow.update_pointmap(Xkk, h.Ckf)
+        h.T_WCf = T_WCf
+        h.frame.T_WC = T_WCf
         h.shadow = shadow
         self._shadow = shadow
 
@@ -140,17 +193,19 @@ class FrameTracker:
         """Reads the verdict (the one host wait of a tracked frame) -> "ok" or "skip".  When the solver needed more than
         the first chunk of iterations (rare) the rest runs now and the optimistic effects are redone from its result;
         `h.replayed` then tells a pipelining caller that a frame begun on top of this one saw stale inputs."""
+        t_wait = time.perf_counter()
         h.event.synchronize()
+        self.verdict_wait_s += time.perf_counter() - t_wait
         v = h.verdict.tolist()
         if v[0] >= self.cfg["min_match_frac"] and int(v[5]) == 0 and int(v[2]) == 0 and int(v[1]) < int(self.cfg["max_iters"]):
             self._cur = h
-            T_WCf, T_CkCf, h.status = self._run_rest()     # rare: the loop needs more than the first chunk
+            _, T_CkCf, h.status = self._run_rest()         # rare: the loop needs more than the first chunk
             self._post_verdict(h)
             h.event.synchronize()
             v = h.verdict.tolist()
             stale = h.shadow
             later = self._shadow if self._shadow is not stale else None
-            self._apply(h, T_WCf, T_CkCf)
+            self._apply(h, None, T_CkCf)
             stale._replaced_by = h.shadow  # an undo that restores the stale shadow gets the redone one (_live)
             if later is not None:          # a frame was begun on top of the stale shadow: its caller rolls it back
                 self._shadow = later
@@ -172,13 +227,20 @@ class FrameTracker:
             return False, [], True
         if h.quality is not None:
             q = h.quality
-            rd_f = point_to_ray_dist(act_Sim3(h.T_CkCf, q["Xf_g"], jacobian=False), jacobian=False)
-            vec = h.T_CkCf.data.view(-1, 8)
-            w = vec[..., 6].clamp(-1.0, 1.0).abs()
+            T_CkCf = h.T_CkCf
+
+            def residual_map(q=q, T=T_CkCf):       # tracker.py:94-127, evaluated by the service when it computes the job
+                Xf_g = q["Xf"][q["idx"]]                              # the reference's Xf is the gathered one (:181-206)
+                rd_k = point_to_ray_dist(q["Xk"], jacobian=False)
+                rd_f = point_to_ray_dist(act_Sim3(T, Xf_g, jacobian=False), jacobian=False)
+                vec = T.data.view(-1, 8)
+                w = vec[..., 6].clamp(-1.0, 1.0).abs()
+                return {"r_pix": torch.linalg.norm(rd_k - rd_f, dim=1), "t_norm": vec[..., :3].norm(dim=-1).mean(),
+                        "theta": (2.0 * torch.arccos(w)).mean()}
+
             self.quality_service.submit({
                 "kf_id": q["kf_id"], "frame_id": q["frame_id"], "H": q["H"], "W": q["W"], "valid_kf": q["valid_kf"],
-                "r_pix": torch.linalg.norm(q["rd_k"] - rd_f, dim=1), "Ck": q["Ck"], "Qk": q["Qk"],
-                "t_norm": vec[..., :3].norm(dim=-1).mean(), "theta": (2.0 * torch.arccos(w)).mean()})
+                "Ck": q["Ck"], "Qk": q["Qk"], "lazy": residual_map, "keep": (q["Xf"], q["idx"], q["Xk"], T_CkCf.data)})
         keyframe = h.shadow
         keyframe.T_WC = self.keyframes.last_keyframe().T_WC      # never write a pose back that a solve has replaced since
         self.keyframes[len(self.keyframes) - 1] = keyframe
@@ -231,7 +293,8 @@ class FrameTracker:
 
     FIRST_CHUNK = 8   # iterations enqueued before the verdict is read; the rest only if the loop has not finished
 
-    def _run_async(self, use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None, chunked=False):
+    def _run_async(self, use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None, chunked=False, T_rel=None,
+                   pose=True):
         """Enqueues the GN loop; returns (T_WCf, T_CkCf, status) with `status` a device i32[8]
         ([done, iterations, failed, ...]) that the caller reads when it needs the verdict.  chunked=True enqueues only
         the first FIRST_CHUNK iterations (a tracked frame needs ~5; 50 launch pairs that exit at once would cost more
@@ -242,7 +305,8 @@ class FrameTracker:
         dev = Xf.device
         idx = self._idx if idx is None else idx
         n = Xk.shape[0]
-        T_rel = (T_WCk.inv() * T_WCf).data.reshape(8).contiguous().clone()
+        if T_rel is None:          # (track_begin passes the one mslam_track_prepare computed)
+            T_rel = (T_WCk.inv() * T_WCf).data.reshape(8).contiguous().clone()
         L = _m.lib()
         need = L.mslam_track_workspace_bytes(n)
         cur = getattr(self, "_cur", None)
@@ -261,7 +325,7 @@ class FrameTracker:
                                _m.ptr(valid_c), n, _m.ptr(K_c) if use_calib else 0,
                                w, h, float(sa), float(sb), float(cfg["huber"]), int(cfg["pixel_border"]),
                                float(cfg["depth_eps"])),
-                         keep=(T_rel, Xf_c, Xk_c, idx_c, Qk_c, valid_c, K_c), T_rel=T_rel, T_WCk=T_WCk, slot=sl)
+                         keep=(T_rel, Xf_c, Xk_c, idx_c, Qk_c, valid_c, K_c), T_rel=T_rel, T_WCk=T_WCk, slot=sl, pose=pose)
         last = min(self.FIRST_CHUNK, int(cfg["max_iters"])) if chunked else int(cfg["max_iters"])
         return self._enqueue(self._job, 0, last)
 
@@ -272,7 +336,7 @@ class FrameTracker:
                                        sl["ws"].numel(), _m.stream_ptr())
         _m.check(rc, "track_pose")
         T_CkCf = Sim3(job["T_rel"].reshape(1, 8))
-        return job["T_WCk"] * T_CkCf, T_CkCf, sl["status"]
+        return (job["T_WCk"] * T_CkCf if job["pose"] else None), T_CkCf, sl["status"]
 
     def _run_rest(self):
         """The iterations behind the first chunk (same loop state, same results as one uninterrupted loop)."""

@@ -50,6 +50,9 @@ _SIGNATURES = {
     "mslam_attention_bf16": [_c_vp] * 4 + [_c_int] * 4 + [_c_vp],
     "mslam_layernorm_f32": [_c_vp] * 5 + [_c_int, _c_int, _c_float, _c_vp],
     "mslam_track_pose": [_c_int] + [_c_vp] * 6 + [_c_int, _c_vp, _c_int, _c_int] + [_c_float] * 3 + [_c_int, _c_float, _c_int, _c_int, _c_float, _c_float, _c_vp, _c_vp, _c_size, _c_vp],
+    "mslam_track_prepare": [_c_vp] * 5 + [_c_float, _c_vp, _c_float, _c_float, _c_float, _c_int] + [_c_vp] * 8 + [_c_size, _c_vp],
+    "mslam_track_verdict": [_c_vp, _c_vp, _c_int, _c_vp, _c_vp],
+    "mslam_track_fuse": [_c_vp] * 6 + [_c_int] + [_c_vp] * 4,
     "mslam_tsdf_local_build": [_c_vp] * 5 + [_c_int] * 4 + [_c_double, _c_double, _c_float, _c_vp, _c_vp, _c_vp, _c_size, _c_vp],
     "mslam_tsdf_local_raycast": [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_float, _c_vp, _c_vp, _c_vp],
     "mslam_quality_reduce_grid": [_c_vp] * 3 + [_c_int] * 4 + [_c_double, _c_double, _c_vp, _c_vp],
@@ -76,6 +79,7 @@ _RESTYPES = {
     "mslam_tsdf_table_bytes": ctypes.c_size_t,
     "mslam_tsdf_local_workspace_bytes": ctypes.c_size_t,
     "mslam_track_workspace_bytes": ctypes.c_size_t,
+    "mslam_track_prepare_workspace_bytes": ctypes.c_size_t,
     "mslam_mast3r_workspace_bytes": ctypes.c_size_t,
     "mslam_tsdf_integrate_workspace_bytes": ctypes.c_size_t,
 }
@@ -109,6 +113,8 @@ def lib() -> ctypes.CDLL:
         handle.mslam_mast3r_workspace_bytes.restype = ctypes.c_size_t
         handle.mslam_track_workspace_bytes.argtypes = [_c_int]
         handle.mslam_track_workspace_bytes.restype = ctypes.c_size_t
+        handle.mslam_track_prepare_workspace_bytes.argtypes = [_c_int]
+        handle.mslam_track_prepare_workspace_bytes.restype = ctypes.c_size_t
         handle.mslam_tsdf_local_workspace_bytes.argtypes = [_c_int]
         handle.mslam_tsdf_local_workspace_bytes.restype = ctypes.c_size_t
         handle.mslam_tsdf_table_bytes.argtypes = [ctypes.c_uint64]

@@ -36,7 +36,7 @@ def test_track_gates_and_fusion(device, golden_dir, monkeypatch, name):
     seen = {}
     pose = lambda k: Sim3(torch.from_numpy(fx[k].astype(np.float32)).reshape(1, 8).to(device))
 
-    def solver(use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None, chunked=False):
+    def solver(use_calib, Xf, Xk, T_WCf, T_WCk, Qk, valid, K, img_size, idx=None, chunked=False, T_rel=None, **_):
         # the enqueue-only form track() uses: (T_WCf, T_CkCf, device status [done, iterations, failed, ...]); track()
         # reaches it even when the match-fraction gate fails (the verdict is read once, after the solve is enqueued)
         seen["Qk"], seen["valid"] = Qk.cpu().numpy(), valid.cpu().numpy()

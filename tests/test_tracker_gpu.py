@@ -69,3 +69,59 @@ def test_tracking_failure_flag(device):
                                           Sim3(t(d["T_WCk"]).reshape(1, 8)), t(d["Qk"]).reshape(-1, 1), none,
                                           idx=t(d["idx"]))
     assert not ok  # H = 0 -> Cholesky fails -> the reference's "Cholesky failed" path
+
+
+@pytest.mark.parametrize("hw", [(48, 64), (384, 512)])
+def test_fused_glue_equals_tensor_expressions(device, hw):
+    """mslam_track_prepare / _verdict / _fuse against the op-by-op tensor expressions of FrameTracker.track they replace
+    (tracker.py:61-75, 147-177; frame.py:72-75 'weighted_pointmap'; lietorch inv / mul / act): bit for bit."""
+    import mslam_hip as m
+    from lietorch_hip import Sim3
+
+    n = hw[0] * hw[1]
+    g = torch.Generator(device="cpu").manual_seed(hw[0])
+    r = lambda *s: torch.rand(*s, generator=g)
+    idx = torch.randint(0, n, (n,), generator=g).to(device)
+    idx[: n // 3] = torch.arange(n // 3, device=device)          # a mix of identity matches and collisions
+    vm = (r(n, 1) > 0.2).to(device)
+    Qff, Qkf = (1.0 + 3.0 * r(n, 1)).to(device), (1.0 + 3.0 * r(n, 1)).to(device)
+    Cf_sum, Ck_sum = (0.5 + 4.0 * r(n, 1)).to(device), (0.5 + 9.0 * r(n, 1)).to(device)
+    Nf, Nk, C_conf, Q_conf = 1, 3, 1.3, 2.1
+    pose = lambda: Sim3.exp((0.3 * (r(1, 7) - 0.5)).to(device))
+    T_WCk, T_WCf = pose(), pose()
+    L = m.lib()
+    ws = torch.empty(L.mslam_track_prepare_workspace_bytes(n), dtype=torch.uint8, device=device)
+    Qk, Ck = torch.empty(n, 1, device=device), torch.empty(n, 1, device=device)
+    vo, vk = torch.empty(n, 1, dtype=torch.bool, device=device), torch.empty(n, 1, dtype=torch.bool, device=device)
+    T_rel = torch.empty(8, device=device)
+    inv = lambda N: float(np.float32(1.0) / np.float32(N))
+    m.check(L.mslam_track_prepare(m.ptr(idx), m.ptr(vm), m.ptr(Qff), m.ptr(Qkf), m.ptr(Cf_sum), inv(Nf), m.ptr(Ck_sum), inv(Nk),
+                                  C_conf, Q_conf, n, m.ptr(T_WCk.data), m.ptr(T_WCf.data), m.ptr(Qk), m.ptr(Ck), m.ptr(vo),
+                                  m.ptr(vk), m.ptr(T_rel), m.ptr(ws), ws.numel(), m.stream_ptr()), "track_prepare")
+    # the tensor expressions (as FrameTracker wrote them before the fusion)
+    Qk_t = torch.sqrt(Qff[idx] * Qkf)
+    Cf_t, Ck_t = (Cf_sum / Nf)[idx], Ck_sum / Nk
+    vQ = Qk_t > Q_conf
+    vo_t, vk_t = vm & (Cf_t > C_conf) & (Ck_t > C_conf) & vQ, vm & vQ
+    hits = torch.zeros(n, dtype=torch.int32, device=device)
+    hits.index_add_(0, idx, vm[:, 0].to(torch.int32))
+    assert torch.equal(Qk, Qk_t) and torch.equal(Ck, Ck_t) and torch.equal(vo, vo_t) and torch.equal(vk, vk_t)
+    assert torch.equal(T_rel, (T_WCk.inv() * T_WCf).data.reshape(8))
+    status = torch.tensor([1, 5, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=device)
+    v6 = torch.empty(6, device=device)
+    m.check(L.mslam_track_verdict(m.ptr(ws), m.ptr(status), n, m.ptr(v6), m.stream_ptr()), "track_verdict")
+    want = torch.stack((vo_t.float().mean(), status[1].float(), status[2].float(), vk_t.float().mean(),
+                        (hits > 0).float().mean(), status[0].float()))
+    assert torch.equal(v6, want), (v6, want)
+    assert 0.05 < float(v6[4]) < 0.95
+    # fusion of the keyframe's pointmap through the solved relative pose
+    Xkf, Ckf = (r(n, 3) * 4 - 2).to(device), (0.5 + 2.0 * r(n, 1)).to(device)
+    Xc = (r(n, 3) * 4 - 2).to(device)
+    T_CkCf = Sim3(T_rel.reshape(1, 8))
+    T_out, X_new, C_new = torch.empty(1, 8, device=device), torch.empty_like(Xc), torch.empty_like(Ck_sum)
+    m.check(L.mslam_track_fuse(m.ptr(T_WCk.data), m.ptr(T_rel), m.ptr(Xkf), m.ptr(Ckf), m.ptr(Xc), m.ptr(Ck_sum), n,
+                               m.ptr(T_out), m.ptr(X_new), m.ptr(C_new), m.stream_ptr()), "track_fuse")
+    Xkk = T_CkCf.act(Xkf)
+    assert torch.equal(T_out, (T_WCk * T_CkCf).data.reshape(1, 8))
+    assert torch.equal(X_new, ((Ck_sum * Xc) + (Ckf * Xkk)) / (Ck_sum + Ckf))
+    assert torch.equal(C_new, Ck_sum + Ckf)
