@@ -91,6 +91,11 @@ def parse():
                     help="run the keyframe backend inline in the tracking loop (the reference's single_thread mode)")
     ap.add_argument("--frame-group", type=int, default=4,
                     help="frames whose network stages run in one batch call (SlamSystem frame groups)")
+    ap.add_argument("--backend-stages", type=int, default=2,
+                    help="threaded backend: 2 = graph stage (retrieval, pair inference, matching) and solve stage (GN, TSDF, "
+                         "local refinement) on threads / streams of their own; 1 = one thread does the whole keyframe task")
+    ap.add_argument("--solve-priority", type=int, default=0,
+                    help="HIP stream priority of the backend's solve stage (-1 = high): a chain of short kernels and host reads")
     ap.add_argument("--encoder-group", type=int, default=0,
                     help="frames per look-ahead encoder call (0 = the frame group)")
     ap.add_argument("--decode-ahead", type=int, default=0,
@@ -204,7 +209,8 @@ class Session:
                                  tsdf_global_cfg=tg, tsdf_refine_cfg=tr, quality_service=qs, decode_ahead=args.decode_ahead,
                                  backend="inline" if args.no_backend_thread else "thread", shard_channel=channel,
                                  pipeline=args.pipeline_depth > 0, pipeline_depth=max(1, args.pipeline_depth),
-                                 backend_priority=args.backend_priority, encoder_priority=args.encoder_priority)
+                                 backend_priority=args.backend_priority, encoder_priority=args.encoder_priority,
+                                 backend_stages=args.backend_stages, solve_priority=args.solve_priority)
         # the stream: RGB frames rendered on the device, resident in HBM before the clock starts
         shp = torch.tensor([[H, W]])
         self.frames = []
@@ -593,6 +599,7 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
     kf0, e0 = ses.graph()
     st0 = dict(ses.system.stats)
     st0["verdict_wait_s"] = ses.system.tracker.verdict_wait_s
+    st0["backend_phase_s"] = dict(st0.get("backend_phase_s", {}))
     rows0 = (ses.model.enc_rows, ses.model.dec_rows)
     M, N, K = dominant_shape(max(B, ses.system.encoder_group))   # the look-ahead encoder's batch
     mslam_hip.check(L.mslam_gemm_profile_begin(M, N, K, 8192), "gemm_profile_begin")
@@ -637,6 +644,10 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
               "the device (tracking verdicts)", file=sys.stderr)
         fps = args.steps * world / elapsed
         new_kf, new_e = kf1 - kf0, e1 - e0
+        if st1.get("backend_phase_s"):   # MSLAM_BACKEND_PROFILE=1: the keyframe task's chain, phase by phase (whole session)
+            ph, ph0 = st1["backend_phase_s"], st0.get("backend_phase_s", {})
+            print(f"[bench] backend phases, ms per keyframe task in the timed region ({new_kf} tasks, {kf0}->{kf1} keyframes): " +
+                  ", ".join(f"{k} {1e3 * (v - ph0.get(k, 0.0)) / max(1, new_kf):.2f}" for k, v in ph.items()), file=sys.stderr)
         # network FLOP actually launched inside the timed region (rows of every encoder / decoder+heads call)
         gflop = 0.0 if args.no_network else enc_rows * ses.gf_enc + dec_rows * (GF_DEC + 2 * GF_HEAD)
         dom_gflop = 2e-9 * M * N * K
@@ -667,7 +678,10 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
                                       "1 000-frame schedule" if preroll else "; no pre-roll: the graph grows from the first frame"),
                        "weights": "random-init ViT-L/12+12 MASt3R architecture (no checkpoint offline); geometry from the "
                                   "procedural room stand-in, rendered on the device inside the timed region",
-                       "backend": "inline" if args.no_backend_thread else "own host thread + stream (as the reference's backend process)",
+                       "backend": "inline" if args.no_backend_thread else (
+                           "own host thread + stream (as the reference's backend process)" if args.backend_stages < 2 else
+                           "two host threads + streams: graph stage of keyframe k+1 beside the solve stage of keyframe k "
+                           "(the reference's backend is a process of its own)"),
                        "frame_group": B, "encoder_group": ses.system.encoder_group, "camera_path_stride": args.stride, "match_frac_thresh": args.kf_thresh,
                        "stats": {"keyframes": kf1, "new_keyframes": new_kf, "new_edges": new_e,
                                  "decoded_rows_tracking": st1["decoded_rows"] - st0["decoded_rows"],

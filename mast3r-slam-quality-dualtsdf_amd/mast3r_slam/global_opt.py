@@ -11,6 +11,8 @@ encoder tokens, 3.1 MB, from the rank that tracked it) and share the backend of 
   block buffers Hs[4,E,7,7] / gs[2,E,7] are summed with ONE all-reduce per GN iteration (RCCL over xGMI on MI355X;
   other ranks' slots are zero so the sum is exact and every rank gets bit-identical blocks), and every rank runs the
   same fp64 solve + retraction - no broadcast."""
+import threading
+
 import torch
 
 import mast3r_slam_backends
@@ -46,6 +48,9 @@ class FactorGraph:
         self.group = channel.group if channel is not None else None
         self._sent_tokens = {}     # keyframe index -> frame_id whose encoder tokens the shards hold
         self._sent_stamp = {}      # keyframe index -> store stamp of the pointmap the shards hold
+        # a two-stage backend appends the next keyframe's edges (graph stage) while the solve stage reads the lists
+        self.lock = threading.Lock()
+        self._pm_cache = None      # stacked pointmaps / confidences of the keyframes, refreshed row by row (prepare_solve)
 
     # ------------------------------------------------------------------
     def add_factors(self, ii, jj, min_match_frac, is_reloc=False):
@@ -142,14 +147,21 @@ class FactorGraph:
         jj_t = torch.as_tensor(jj, device=self.device)
         invalid = torch.minimum(match_frac_j, match_frac_i) < min_match_frac
         invalid = (~(ii_t == (jj_t - 1))) & invalid
-        if invalid.any() and is_reloc:
+        keep = (~invalid).cpu().tolist()          # the ONE host read of the call (a boolean-mask index would be one each)
+        if is_reloc and not all(keep):
             return False
-        ok = ~invalid
-        for name, rows in (("ii", ii_t[ok]), ("jj", jj_t[ok]), ("idx_ii2jj", idx_i2j[ok]), ("idx_jj2ii", idx_j2i[ok]),
-                           ("valid_match_j", valid_match_j[ok]), ("valid_match_i", valid_match_i[ok]),
-                           ("Q_ii2jj", Qj[ok]), ("Q_jj2ii", Qi[ok])):
-            self._rows[name].append(rows)
-        return ok.sum() > 0
+        if all(keep):
+            sel = lambda t: t
+        else:
+            rows_kept = torch.tensor([r for r, k in enumerate(keep) if k], dtype=torch.long, device=ii_t.device)
+            sel = lambda t: t.index_select(0, rows_kept)
+        picked = [("ii", sel(ii_t)), ("jj", sel(jj_t)), ("idx_ii2jj", sel(idx_i2j)), ("idx_jj2ii", sel(idx_j2i)),
+                  ("valid_match_j", sel(valid_match_j)), ("valid_match_i", sel(valid_match_i)),
+                  ("Q_ii2jj", sel(Qj)), ("Q_jj2ii", sel(Qi))]
+        with self.lock:
+            for name, rows in picked:
+                self._rows[name].append(rows)
+        return any(keep)
 
     ii = property(lambda self: self._rows["ii"].view)
     jj = property(lambda self: self._rows["jj"].view)
@@ -160,16 +172,23 @@ class FactorGraph:
     Q_ii2jj = property(lambda self: self._rows["Q_ii2jj"].view)
     Q_jj2ii = property(lambda self: self._rows["Q_jj2ii"].view)
 
-    def two_way_sources(self):
+    @property
+    def n_edges(self):
+        return self._rows["ii"].n
+
+    def two_way_sources(self, n_edges=None):
         """The two-way edge set of prep_two_way_edges WITHOUT the concatenation of the big arrays: (ii, jj) of all 2E
         directed edges (tiny) and the per-edge inputs as the two blocks they are stored in, in the reference's order
-        (forward edges, then backward): [(idx, valid, Q) of edges [0, E), (idx, valid, Q) of edges [E, 2E)]."""
-        ii = torch.cat((self.ii, self.jj), dim=0)
-        jj = torch.cat((self.jj, self.ii), dim=0)
-        return ii, jj, [(self.idx_ii2jj, self.valid_match_j, self.Q_ii2jj), (self.idx_jj2ii, self.valid_match_i, self.Q_jj2ii)]
+        (forward edges, then backward): [(idx, valid, Q) of edges [0, E), (idx, valid, Q) of edges [E, 2E)].
+        `n_edges`: only the first n_edges undirected edges (the graph as it stood when they had been added)."""
+        v = lambda name: self._rows[name].view if n_edges is None else self._rows[name].view[:n_edges]
+        ii = torch.cat((v("ii"), v("jj")), dim=0)
+        jj = torch.cat((v("jj"), v("ii")), dim=0)
+        return ii, jj, [(v("idx_ii2jj"), v("valid_match_j"), v("Q_ii2jj")), (v("idx_jj2ii"), v("valid_match_i"), v("Q_jj2ii"))]
 
-    def get_unique_kf_idx(self):
-        return torch.unique(torch.cat([self.ii, self.jj]), sorted=True)
+    def get_unique_kf_idx(self, n_edges=None):
+        ii, jj = (self.ii, self.jj) if n_edges is None else (self.ii[:n_edges], self.jj[:n_edges])
+        return torch.unique(torch.cat([ii, jj]), sorted=True)
 
     def prep_two_way_edges(self):
         """global_opt.py:106-112."""
@@ -187,25 +206,65 @@ class FactorGraph:
         Cs = torch.stack([kf.get_average_conf() for kf in kfs])
         return Xs, T_WCs, Cs
 
+    def _poses_points_cached(self, ids):
+        """get_poses_points for a store that stamps its keyframes (KeyframeStore / SharedKeyframes.stamp): the stacked
+        pointmaps / average confidences live in a persistent buffer and only the rows whose keyframe changed since the
+        last solve are rewritten - the reference (and get_poses_points) restacks all P keyframes per solve (P x 3.1 MB and
+        P small launches inside the hand-over section).  The buffer is written and read on the solving stream only, so
+        the previous solve's kernels are ordered in front of the next refresh."""
+        stamp = self.frames.stamp
+        kfs = [self.frames[i] for i in ids]
+        P, shp, dev = len(kfs), tuple(kfs[0].X_canon.shape), kfs[0].X_canon.device
+        c = self._pm_cache
+        if c is None or c["shape"] != shp or c["X"].device != dev or c["X"].shape[0] < P:
+            cap = max(64, 2 * P)
+            new = dict(shape=shp, X=torch.empty((cap,) + shp, dtype=torch.float32, device=dev),
+                       C=torch.empty((cap, shp[0], 1), dtype=torch.float32, device=dev), keys=[None] * cap)
+            if c is not None and c["shape"] == shp and c["X"].device == dev:
+                n = c["X"].shape[0]
+                new["X"][:n], new["C"][:n], new["keys"][:n] = c["X"], c["C"], c["keys"]
+            c = self._pm_cache = new
+        for r, (i, kf) in enumerate(zip(ids, kfs)):
+            key = (int(i), stamp(i))
+            if c["keys"][r] != key:
+                c["X"][r].copy_(kf.X_canon)
+                c["C"][r].copy_(kf.get_average_conf())
+                c["keys"][r] = key
+        T_WCs = Sim3(torch.stack([kf.T_WC.data for kf in kfs]))
+        return c["X"][:P], T_WCs, c["C"][:P]
+
     # ------------------------------------------------------------------
     # The solve in three phases so that a threaded owner (SlamSystem backend="thread") can hold its hand-over lock
     # only around the two short ones: prepare() READS the keyframe store (copies: stack / contiguous), run() works
     # on those copies alone, commit() WRITES the optimised poses back (global_opt.py:145-164 does all three in line).
-    def prepare_solve(self, kind):
+    def prepare_solve(self, kind, n_edges=None):
+        """`n_edges`: solve over the first n_edges (undirected) edges only - the graph of the keyframe task this solve
+        belongs to, while a later task's edges may already have been appended by the graph stage."""
         pin = self.cfg["pin"]
-        unique_kf_idx = self.get_unique_kf_idx()
+        with self.lock:
+            if n_edges is not None:
+                n_edges = min(int(n_edges), self.n_edges)
+            unique_kf_idx = self.get_unique_kf_idx(n_edges)
+            ii, jj, sources = self.two_way_sources(n_edges)
         if unique_kf_idx.numel() <= pin:
             self.last_unique_kf_idx = None
             return None
-        Xs, T_WCs, Cs = self.get_poses_points(unique_kf_idx)
+        if ii.is_cuda:      # the lists were allocated (and may be re-allocated) on the graph stage's stream
+            cur = torch.cuda.current_stream(ii.device)
+            for blk in sources:
+                for t in blk:
+                    t.record_stream(cur)
         self.last_unique_kf_idx = unique_kf_idx.detach().cpu()
+        if hasattr(self.frames, "stamp"):
+            Xs, T_WCs, Cs = self._poses_points_cached(self.last_unique_kf_idx.tolist())
+        else:
+            Xs, T_WCs, Cs = self.get_poses_points(unique_kf_idx)
         K = self.K
         height = width = 0
         if kind == "calib":
             img_size = self.frames[0].img.shape[-2:]
             Xs = constrain_points_to_ray(img_size, Xs, K)
             height, width = int(img_size[0]), int(img_size[1])
-        ii, jj, sources = self.two_way_sources()
         job = dict(kind=kind, pin=pin, unique_kf_idx=unique_kf_idx, unique_kf_idx_host=self.last_unique_kf_idx, K=K,
                    height=height, width=width,
                    pose_data=T_WCs.data[:, 0, :].contiguous(), Xs=Xs.contiguous(), Cs=Cs.contiguous(),

@@ -20,6 +20,9 @@ from mast3r_slam.quality_core import compute_batch
 def _prep_job(j, dev):
     """quality_async.py:12-46.  A job may carry its residual map as a deferred expression (`lazy`, FrameTracker): it is
     evaluated here, i.e. only for the jobs that are actually computed."""
+    ev = j.get("event")
+    if ev is not None:                           # the job's tensors were produced on the submitting thread's stream
+        torch.cuda.current_stream().wait_event(ev)
     if "lazy" in j:
         j = dict(j)
         if torch.cuda.is_available():
@@ -69,6 +72,9 @@ class SynchronousQualityService:
     def submit(self, job):
         """quality_async.py:107-117: the keyframe's persisted coverage EWMA rides along.  A newer job for the same
         keyframe replaces a queued one (the result cache is keyed by keyframe anyway)."""
+        if torch.cuda.is_available() and any(torch.is_tensor(v) and v.is_cuda for v in job.values()):
+            job["event"] = torch.cuda.Event()
+            job["event"].record()
         with self.lock:
             kf_id = job.get("kf_id")
             if kf_id is not None and kf_id in self.ewma_state:

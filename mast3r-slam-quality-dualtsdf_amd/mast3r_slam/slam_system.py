@@ -23,6 +23,7 @@ Retrieval (retrieval_database.py, ASMK) is not available offline; `retriever` is
 `update(frame, add_after_query, k, min_thresh) -> [keyframe ids]`.  The default stand-in proposes no loop-closure edges
 and offers the most recent keyframes as relocalisation candidates."""
 import contextlib
+import os
 import queue
 import threading
 import time
@@ -52,42 +53,60 @@ class RecentKeyframes:
 
 
 class _BackendThread(threading.Thread):
-    """run_backend (main.py:73-163) as a host thread with its own stream; tasks are keyframe indices."""
+    """One stage of run_backend (main.py:73-163) as a host thread with its own stream.  Tasks are (keyframe index, event
+    the stage's stream waits for, payload of the previous stage); `fn(idx, payload)` does the stage's work and its return
+    value travels to `next_stage` behind an event recorded on this stage's stream."""
 
-    def __init__(self, system):
+    def __init__(self, system, fn, next_stage=None, priority=0):
         super().__init__(daemon=True)
-        self.system, self.q, self.error = system, queue.Queue(), None
+        self.system, self.fn, self.next_stage, self.priority = system, fn, next_stage, int(priority)
+        self.q, self.error = queue.Queue(), None
         self.start()
 
     def run(self):
         dev = self.system.device
         torch.cuda.set_device(dev)
-        with torch.cuda.stream(torch.cuda.Stream(device=dev, priority=self.system.backend_priority)):
+        with torch.cuda.stream(torch.cuda.Stream(device=dev, priority=self.priority)):
             while True:
                 task = self.q.get()
                 try:
                     if task is None:
                         return
                     if self.error is None:
-                        idx, ev = task
-                        torch.cuda.current_stream(dev).wait_event(ev)   # the keyframe was produced on the tracking stream
-                        self.system._backend(idx)
+                        idx, ev, payload = task
+                        stream = torch.cuda.current_stream(dev)
+                        stream.wait_event(ev)              # what the task reads was produced on another stream
+                        out = self.fn(idx, payload)
+                        if self.next_stage is not None:
+                            done = torch.cuda.Event()
+                            done.record(stream)
+                            self.next_stage.q.put((idx, done, out))
                 except Exception as e:   # surfaced by drain()
                     self.error = e
                 finally:
                     self.q.task_done()
 
     def drain(self):
-        self.q.join()
+        self.q.join()                    # every task of this stage has been handed on before it counts as done
         if self.error is not None:
             raise self.error
+        if self.next_stage is not None:
+            self.next_stage.drain()
+
+    def stop(self):
+        st = self
+        while st is not None:
+            st.q.put(None)
+            st.join(timeout=5.0)
+            st = st.next_stage
 
 
 class SlamSystem:
     def __init__(self, model, device, K=None, keyframes=None, retriever=None, frame_group=1, tsdf_global_cfg=None,
                  encoder_group=None,
                  backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0,
-                 shard_channel=None, pipeline=False, pipeline_depth=1, backend_priority=0, encoder_priority=0):
+                 shard_channel=None, pipeline=False, pipeline_depth=1, backend_priority=0, encoder_priority=0,
+                 backend_stages=2, solve_priority=0):
         """`shard_channel` (mast3r_slam/shard.py): this process is the DRIVER rank of a session whose backend is sharded
         over the ranks of the channel's group - keyframe-pair inference + matching, the global GN (one all-reduce per
         iteration) and the global TSDF's voxels; the other ranks run BackendShard.serve()."""
@@ -119,10 +138,25 @@ class SlamSystem:
             self.tsdf_refiner.start()
         assert backend in ("inline", "thread")
         self._lock = threading.RLock()
+        self._bprof = bool(os.environ.get("MSLAM_BACKEND_PROFILE"))
         self._hand = {"main": None, "backend": None}   # event at the end of each side's last critical section
         self._commits = []                              # (solve job, event): optimised poses waiting to be written back
         self._backend_done = None                       # event behind the last backend task (threaded backend)
-        self._worker = _BackendThread(self) if backend == "thread" else None
+        # backend="thread", two stages (default): the graph stage of keyframe k+1 (retrieval + symmetric inference +
+        # matching: throughput-bound network launches) runs beside the solve stage of keyframe k (global GN, TSDF hook,
+        # local refinement: a dependent chain of short kernels and host reads) on threads / streams of their own - the
+        # keyframe task's chain (64 ms per keyframe at 60-120 keyframes, of which 27 ms network) was what bound the loop.
+        # Every solve still sees exactly the edges of the tasks up to its own (the edge count travels with the task).
+        # A sharded session keeps ONE backend thread: its collectives must be issued in one order on every rank.
+        self._worker = None
+        self._graph_done = None
+        if backend == "thread":
+            if int(backend_stages) >= 2 and shard_channel is None:
+                solve = _BackendThread(self, lambda idx, n_edges: self._backend_solve(idx, n_edges), priority=solve_priority)
+                self._worker = _BackendThread(self, lambda idx, _: self._backend_graph(idx), next_stage=solve,
+                                              priority=self.backend_priority)
+            else:
+                self._worker = _BackendThread(self, lambda idx, _: self._backend(idx), priority=self.backend_priority)
         self.mode = Mode.INIT
         self.last_T = None
         self.frame_group = max(1, int(frame_group))
@@ -272,10 +306,7 @@ class SlamSystem:
                 add_new_kf = True
                 self.mode = Mode.TRACKING
             elif mode == Mode.TRACKING:                 # main.py:369-373
-                add_new_kf, _, try_reloc = self.tracker.track(frame)
-                if try_reloc:
-                    self.mode = Mode.RELOC
-                self._note_keyframe_rule(add_new_kf or try_reloc)
+                h = self.tracker.track_begin(frame)
             elif mode == Mode.RELOC:                    # main.py:375-385
                 self.tracker._shadow = None             # whatever comes next is tracked against the store's keyframe
                 X, C = mu.mast3r_inference_mono(self.model, frame)
@@ -285,10 +316,24 @@ class SlamSystem:
                     self.stats["relocalised"] += 1
             else:
                 raise Exception("Invalid mode")
-            self.last_T = frame.T_WC
-            if add_new_kf:                              # main.py:387-395
-                self.keyframes.append(frame)
-                self.stats["keyframes"] += 1
+            if mode != Mode.TRACKING:
+                self.last_T = frame.T_WC
+                if add_new_kf:                          # main.py:387-395
+                    self.keyframes.append(frame)
+                    self.stats["keyframes"] += 1
+        if mode == Mode.TRACKING:
+            # the one host wait of a tracked frame happens OUTSIDE the hand-over section: the backend's solve stage can copy
+            # keyframe data out (or write poses back) while this thread sleeps on the verdict
+            self.tracker.track_resolve(h)
+            with self._critical("main"):
+                add_new_kf, _, try_reloc = self.tracker.track_finish(h)
+                if try_reloc:
+                    self.mode = Mode.RELOC
+                self._note_keyframe_rule(add_new_kf or try_reloc)
+                self.last_T = frame.T_WC
+                if add_new_kf:                          # main.py:387-395
+                    self.keyframes.append(frame)
+                    self.stats["keyframes"] += 1
         if add_new_kf:
             self._queue_backend(len(self.keyframes) - 1)
         return dict(mode=mode, new_kf=bool(add_new_kf), try_reloc=bool(try_reloc), pose=frame.T_WC.data.clone())
@@ -297,6 +342,10 @@ class SlamSystem:
         """Wait until every queued backend task has been issued and its poses are written back (backend="thread")."""
         if self._worker is not None:
             self._worker.drain()
+            main = torch.cuda.current_stream(self.device)
+            for ev in (self._backend_done, self._graph_done):   # the stages' last launches (the refiner's edits, the edge
+                if ev is not None:                               # lists) lie behind their last hand-over section
+                    main.wait_event(ev)
             with self._critical("main"):
                 self._apply_commits(wait=True)
 
@@ -305,8 +354,9 @@ class SlamSystem:
         allocated and last written on the backend stream: the tracking stream first waits for everything the (now idle)
         backend thread has enqueued, and the caching allocator is told that these blocks are in use on this stream too."""
         main = torch.cuda.current_stream(self.device)
-        if self._backend_done is not None:
-            main.wait_event(self._backend_done)
+        for ev in (self._backend_done, self._graph_done):
+            if ev is not None:
+                main.wait_event(ev)
         fg = self.factor_graph
         for t in (fg.ii, fg.jj, fg.idx_ii2jj, fg.idx_jj2ii, fg.valid_match_j, fg.valid_match_i, fg.Q_ii2jj, fg.Q_jj2ii):
             if t.is_cuda and t.numel():
@@ -332,8 +382,7 @@ class SlamSystem:
     def shutdown(self):
         if self._worker is not None:
             self._worker.drain()
-            self._worker.q.put(None)
-            self._worker.join(timeout=5.0)
+            self._worker.stop()
             self._worker = None
         if self.tsdf_manager is not None:
             self.tsdf_manager.shutdown()
@@ -364,7 +413,7 @@ class SlamSystem:
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        self._worker.q.put((idx, ev))
+        self._worker.q.put((idx, ev, None))
 
     # ------------------------------------------------------------------ frame groups
     def _note_keyframe_rule(self, changed):
@@ -479,8 +528,25 @@ class SlamSystem:
         self.stats["decoded_rows"] += len(window)
 
     # ------------------------------------------------------------------ backend (main.py:73-163, 28-71)
+    def _phase(self, name, t0):
+        """MSLAM_BACKEND_PROFILE=1 (diagnostic): wall time per backend phase, each closed by a stream synchronise - what
+        the keyframe task's dependent chain costs, phase by phase, beside a running frontend."""
+        if not self._bprof:
+            return t0
+        torch.cuda.current_stream(self.device).synchronize()
+        t1 = time.perf_counter()
+        acc = self.stats.setdefault("backend_phase_s", {})
+        acc[name] = acc.get(name, 0.0) + (t1 - t0)
+        return t1
+
     def _backend(self, idx):
         """The body of run_backend's loop for the keyframe `idx` (graph construction, global GN, TSDF hook)."""
+        self._backend_solve(idx, self._backend_graph(idx))
+
+    def _backend_graph(self, idx):
+        """First half of the keyframe task (main.py:118-143): retrieval, symmetric edge inference + matching, the new
+        edges appended -> the number of edges the graph holds with this task's (the solve of this task uses those)."""
+        t0 = time.perf_counter()
         kf_idx = []
         n_consec = 1
         for j in range(min(n_consec, idx)):
@@ -493,29 +559,46 @@ class SlamSystem:
         kf_idx.discard(idx)
         kf_idx = list(kf_idx)
         frame_idx = [idx] * len(kf_idx)
+        t0 = self._phase("retrieval", t0)
         if kf_idx:   # symmetric edge inference + matching: reads only the keyframes' (immutable) features
             self.factor_graph.add_factors(kf_idx, frame_idx, config["local_opt"]["min_match_frac"])
+        self._phase("add_factors", t0)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self._graph_done = done
+        return self.factor_graph.n_edges
+
+    def _backend_solve(self, idx, n_edges):
+        """Second half (main.py:145-163 + the TSDF hook + main.py:403-421): global GN over the graph as it stood when
+        this keyframe's edges had been added, TSDF fusion, local refinement."""
+        t0 = time.perf_counter()
         kind = "calib" if config["use_calib"] else "rays"
         if self._worker is None:     # inline: the reference's single_thread order, everything in sequence
             self._solve()
+            t0 = self._phase("solve", t0)
             if self.tsdf_manager is not None:
                 self.tsdf_manager.on_after_backend_solve(self.factor_graph)
+            t0 = self._phase("tsdf", t0)
             self._refine(idx)
+            self._phase("refine", t0)
             return
         # threaded: the lock (and with it the tracking stream) is held only while keyframe data is copied out; the
         # solve and the fusions run on the copies; the poses are written back by the tracking side (_apply_commits)
         mgr = self.tsdf_manager
         with self._critical("backend"):
-            job = self.factor_graph.prepare_solve(kind)
+            t0 = self._phase("lock_wait", t0)
+            job = self.factor_graph.prepare_solve(kind, n_edges=n_edges)
             if job is not None:
                 self._chain_pending_poses(job)
             plan = mgr.plan(self.factor_graph) if mgr is not None else None
+            t0 = self._phase("prepare+plan", t0)
         if job is not None:
             self.factor_graph.run_solve(job)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             with self._lock:
                 self._commits.append((job, ev))
+        t0 = self._phase("solve", t0)
         if plan is not None:
             if job is not None:      # the fusions use the poses THIS solve produced, as the inline order does
                 mgr.retarget(plan, job["unique_kf_idx_host"], job["pose_data"])
@@ -527,10 +610,13 @@ class SlamSystem:
                 with self._critical("backend"):
                     self._apply_commits(wait=True)
                     mgr.execute(plan)
+        t0 = self._phase("tsdf", t0)
         if self.tsdf_refiner is not None:
-            torch.cuda.current_stream(self.device).synchronize()   # outside the lock: the refiner reads scalars back
-            with self._critical("backend"):
-                self._refine(idx)
+            # no hand-over section: the refiner works on keyframes that have LEFT the sliding window (the tracking side
+            # reads and replaces only the newest one), on this thread's stream like the solves and fusions that read its
+            # edits; quality jobs carry the event of the stream that produced their tensors
+            self._refine(idx)
+            t0 = self._phase("refine", t0)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         self._backend_done = done
