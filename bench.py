@@ -91,9 +91,10 @@ def parse():
                     help="run the keyframe backend inline in the tracking loop (the reference's single_thread mode)")
     ap.add_argument("--frame-group", type=int, default=4,
                     help="frames whose network stages run in one batch call (SlamSystem frame groups)")
-    ap.add_argument("--backend-stages", type=int, default=2,
-                    help="threaded backend: 2 = graph stage (retrieval, pair inference, matching) and solve stage (GN, TSDF, "
-                         "local refinement) on threads / streams of their own; 1 = one thread does the whole keyframe task")
+    ap.add_argument("--backend-stages", type=int, default=3,
+                    help="threaded backend: stages of the keyframe task on threads / streams of their own - graph stage "
+                         "(retrieval, pair inference, matching) | solve stage (global GN) | fusion stage (TSDF, local "
+                         "refinement; 2 = together with the solve); 1 = one thread does the whole keyframe task")
     ap.add_argument("--solve-priority", type=int, default=0,
                     help="HIP stream priority of the backend's solve stage (-1 = high): a chain of short kernels and host reads")
     ap.add_argument("--encoder-group", type=int, default=0,
@@ -680,8 +681,9 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
                                   "procedural room stand-in, rendered on the device inside the timed region",
                        "backend": "inline" if args.no_backend_thread else (
                            "own host thread + stream (as the reference's backend process)" if args.backend_stages < 2 else
-                           "two host threads + streams: graph stage of keyframe k+1 beside the solve stage of keyframe k "
-                           "(the reference's backend is a process of its own)"),
+                           f"{args.backend_stages} host threads + streams: graph stage (retrieval, pair inference, matching) of keyframe k+1 "
+                           "beside the solve stage of keyframe k" + (" beside the TSDF fusion + local refinement of keyframe k-1" if args.backend_stages >= 3 else "") +
+                           " (the reference's backend is a process of its own)"),
                        "frame_group": B, "encoder_group": ses.system.encoder_group, "camera_path_stride": args.stride, "match_frac_thresh": args.kf_thresh,
                        "stats": {"keyframes": kf1, "new_keyframes": new_kf, "new_edges": new_e,
                                  "decoded_rows_tracking": st1["decoded_rows"] - st0["decoded_rows"],

@@ -106,7 +106,7 @@ class SlamSystem:
                  encoder_group=None,
                  backend="inline", tsdf_refine_cfg=None, quality_service=None, shard_edges=False, decode_ahead=0,
                  shard_channel=None, pipeline=False, pipeline_depth=1, backend_priority=0, encoder_priority=0,
-                 backend_stages=2, solve_priority=0):
+                 backend_stages=3, solve_priority=0):
         """`shard_channel` (mast3r_slam/shard.py): this process is the DRIVER rank of a session whose backend is sharded
         over the ranks of the channel's group - keyframe-pair inference + matching, the global GN (one all-reduce per
         iteration) and the global TSDF's voxels; the other ranks run BackendShard.serve()."""
@@ -135,24 +135,30 @@ class SlamSystem:
             from mast3r_slam.tsdf_refine import TSDFRefiner
 
             self.tsdf_refiner = TSDFRefiner(tsdf_refine_cfg, self.keyframes, quality_service, device)
+            self.tsdf_refiner.edit_section = lambda: self._critical("refine")
             self.tsdf_refiner.start()
         assert backend in ("inline", "thread")
         self._lock = threading.RLock()
         self._bprof = bool(os.environ.get("MSLAM_BACKEND_PROFILE"))
-        self._hand = {"main": None, "backend": None}   # event at the end of each side's last critical section
+        self._hand = {"main": None, "backend": None, "refine": None}   # event at the end of each party's last critical section
         self._commits = []                              # (solve job, event): optimised poses waiting to be written back
         self._backend_done = None                       # event behind the last backend task (threaded backend)
-        # backend="thread", two stages (default): the graph stage of keyframe k+1 (retrieval + symmetric inference +
-        # matching: throughput-bound network launches) runs beside the solve stage of keyframe k (global GN, TSDF hook,
-        # local refinement: a dependent chain of short kernels and host reads) on threads / streams of their own - the
-        # keyframe task's chain (64 ms per keyframe at 60-120 keyframes, of which 27 ms network) was what bound the loop.
+        # backend="thread", staged (default 3): the graph stage of keyframe k+1 (retrieval + symmetric inference +
+        # matching: throughput-bound network launches) runs beside the solve stage of keyframe k (global GN: a dependent
+        # chain of short kernels) and the fusion / refinement stage of keyframe k-1 (TSDF hook, local refinement: short
+        # launches with host reads in between), each on a thread / stream of its own - the keyframe task's chain (64 ms
+        # per keyframe at 60-120 keyframes, of which 27 ms network) was what bound the loop.
         # Every solve still sees exactly the edges of the tasks up to its own (the edge count travels with the task).
         # A sharded session keeps ONE backend thread: its collectives must be issued in one order on every rank.
         self._worker = None
         self._graph_done = None
         if backend == "thread":
             if int(backend_stages) >= 2 and shard_channel is None:
-                solve = _BackendThread(self, lambda idx, n_edges: self._backend_solve(idx, n_edges), priority=solve_priority)
+                post = None
+                if int(backend_stages) >= 3:     # TSDF fusion + local refinement (host reads) behind the solve, on their own
+                    post = _BackendThread(self, lambda idx, payload: self._backend_post(idx, payload), priority=solve_priority)
+                solve = _BackendThread(self, lambda idx, n_edges: self._backend_solve(idx, n_edges, hand_on=post is not None),
+                                       next_stage=post, priority=solve_priority)
                 self._worker = _BackendThread(self, lambda idx, _: self._backend_graph(idx), next_stage=solve,
                                               priority=self.backend_priority)
             else:
@@ -343,9 +349,9 @@ class SlamSystem:
         if self._worker is not None:
             self._worker.drain()
             main = torch.cuda.current_stream(self.device)
-            for ev in (self._backend_done, self._graph_done):   # the stages' last launches (the refiner's edits, the edge
-                if ev is not None:                               # lists) lie behind their last hand-over section
-                    main.wait_event(ev)
+            for ev in (self._backend_done, self._graph_done, self._hand["backend"], self._hand["refine"]):
+                if ev is not None:           # the stages' last launches (the refiner's edits, the edge lists) lie
+                    main.wait_event(ev)      # behind their last hand-over sections
             with self._critical("main"):
                 self._apply_commits(wait=True)
 
@@ -390,16 +396,17 @@ class SlamSystem:
     @contextlib.contextmanager
     def _critical(self, me):
         """Section that reads or writes keyframe pointmaps / poses.  Inline backend: nothing to do.  Threaded backend:
-        one side at a time (host lock), and the entering side's stream first waits for the event the other side
-        recorded when it left its last section, so data written on one stream is visible to the other."""
+        one party at a time (host lock; parties: "main" = tracking, "backend" = the solve stage, "refine" = the fusion /
+        refinement stage), and the entering party's stream first waits for the events the OTHER parties recorded when they
+        left their last sections, so data written on one stream is visible to the others."""
         if self._worker is None:
             yield
             return
-        other = "backend" if me == "main" else "main"
         with self._lock:
             stream = torch.cuda.current_stream(self.device)
-            if self._hand[other] is not None:
-                stream.wait_event(self._hand[other])
+            for other, ev in self._hand.items():
+                if other != me and ev is not None:
+                    stream.wait_event(ev)
             try:
                 yield
             finally:
@@ -568,9 +575,9 @@ class SlamSystem:
         self._graph_done = done
         return self.factor_graph.n_edges
 
-    def _backend_solve(self, idx, n_edges):
-        """Second half (main.py:145-163 + the TSDF hook + main.py:403-421): global GN over the graph as it stood when
-        this keyframe's edges had been added, TSDF fusion, local refinement."""
+    def _backend_solve(self, idx, n_edges, hand_on=False):
+        """Second half (main.py:145-163): global GN over the graph as it stood when this keyframe's edges had been added;
+        then (or on the next stage's thread, `hand_on`) the TSDF hook and the local refinement (_backend_post)."""
         t0 = time.perf_counter()
         kind = "calib" if config["use_calib"] else "rays"
         if self._worker is None:     # inline: the reference's single_thread order, everything in sequence
@@ -581,7 +588,7 @@ class SlamSystem:
             t0 = self._phase("tsdf", t0)
             self._refine(idx)
             self._phase("refine", t0)
-            return
+            return None
         # threaded: the lock (and with it the tracking stream) is held only while keyframe data is copied out; the
         # solve and the fusions run on the copies; the poses are written back by the tracking side (_apply_commits)
         mgr = self.tsdf_manager
@@ -598,27 +605,48 @@ class SlamSystem:
             ev.record(torch.cuda.current_stream(self.device))
             with self._lock:
                 self._commits.append((job, ev))
-        t0 = self._phase("solve", t0)
+        self._phase("solve", t0)
+        payload = (plan, job)
+        if hand_on:
+            return payload
+        self._backend_post(idx, payload)
+        return None
+
+    def _backend_post(self, idx, payload):
+        """The TSDF hook of the keyframe task (fusions at the poses its solve produced) and the local refinement
+        (main.py:403-421).  With three backend stages this runs on a thread / stream of its own: both are chains of short
+        launches with host reads in between, which would otherwise hold up the next solve."""
+        t0 = time.perf_counter()
+        plan, job = payload
+        mgr = self.tsdf_manager
+        cur = torch.cuda.current_stream(self.device)
         if plan is not None:
+            for _, _, snap in plan["todo"]:        # copies taken on the solve stage's stream, read (and dropped) here
+                for t in (snap or ()):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)
             if job is not None:      # the fusions use the poses THIS solve produced, as the inline order does
+                job["pose_data"].record_stream(cur)
                 mgr.retarget(plan, job["unique_kf_idx_host"], job["pose_data"])
             if not mgr.has_pose_refinement(plan):
                 mgr.execute(plan)            # fusions only: on the copies, outside the lock
             else:
                 # the TSDF pose optimiser reads and writes keyframe poses in the store: inside the hand-over section,
                 # behind this solve's own write-back (rare configuration: the tracking stream waits for the solve here)
-                with self._critical("backend"):
+                with self._critical("refine"):
                     self._apply_commits(wait=True)
                     mgr.execute(plan)
         t0 = self._phase("tsdf", t0)
         if self.tsdf_refiner is not None:
-            # no hand-over section: the refiner works on keyframes that have LEFT the sliding window (the tracking side
-            # reads and replaces only the newest one), on this thread's stream like the solves and fusions that read its
-            # edits; quality jobs carry the event of the stream that produced their tensors
+            # the refiner works on keyframes that have LEFT the sliding window (the tracking side reads and replaces only
+            # the newest one): no section around the whole pass - an empty one orders this stream behind the other parties'
+            # last writes (poses), and the refiner's in-place edit of a keyframe is a section of its own (edit_section)
+            with self._critical("refine"):
+                pass
             self._refine(idx)
             t0 = self._phase("refine", t0)
         done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(self.device))
+        done.record(cur)
         self._backend_done = done
 
     def _chain_pending_poses(self, job):

@@ -5,6 +5,7 @@ scheduling surface main.py drives (lines 246-429: `.start/.queue/.stats/.stop_fl
 loops run as HIP kernels (csrc/tsdf_local.hip).  The reference class is a daemon thread that drains `.queue`; here the
 same loop body is `process_queue()`, called synchronously by the owner (SlamSystem's backend) - no thread, no sleeps,
 no time-based retry back-off (a deferred keyframe is retried at the next call)."""
+import contextlib
 import dataclasses
 import math
 import queue
@@ -103,6 +104,7 @@ class TSDFRefiner:
         self.device = torch.device(device)
         self.keyframes = shared_keyframes
         self.quality_service = quality_service
+        self.edit_section = contextlib.nullcontext     # context manager factory around the in-place edit of a keyframe
         self.versions = {}
         self._ws = None
         self.registry = RefineRegistry({"cooldown_frames": int(self.cfg.get("cooldown_frames", 35))})
@@ -427,18 +429,19 @@ class TSDFRefiner:
         if self._version(block.kf_id) != start_version:   # optimistic version check (:790-794)
             return False, hit_ratio
         boost, cmax = float(cfg.get("confidence_boost", 0.08)), float(cfg.get("confidence_max", 1.3))
-        if kf.C.ndim == 2:
-            kf.C[mask_hits, 0] += boost
-        else:
-            kf.C[mask_hits] += boost
-        kf.C.clamp_(max=cmax)
-        gw = float(cfg.get("geometric_weight", 0.0))
-        if gw > 0:
-            kf.X_canon[mask_hits] = ((1 - gw) * X_canon + gw * X_refined)[mask_hits]
-        self._bump_version(block.kf_id, start_version + 1)
-        touch = getattr(self.keyframes, "touch", None)      # the tensors were edited in place: a sharded backend re-sends them
-        if touch is not None:
-            touch(block.kf_id)
+        with self.edit_section():       # the in-place edit of the keyframe (a threaded owner makes it a hand-over section)
+            if kf.C.ndim == 2:
+                kf.C[mask_hits, 0] += boost
+            else:
+                kf.C[mask_hits] += boost
+            kf.C.clamp_(max=cmax)
+            gw = float(cfg.get("geometric_weight", 0.0))
+            if gw > 0:
+                kf.X_canon[mask_hits] = ((1 - gw) * X_canon + gw * X_refined)[mask_hits]
+            self._bump_version(block.kf_id, start_version + 1)
+            touch = getattr(self.keyframes, "touch", None)      # edited in place: whoever caches the tensors re-reads them
+            if touch is not None:
+                touch(block.kf_id)
         return True, max(hit_ratio, geometric_gain)
 
     # per-keyframe version counter: SharedKeyframes.version (frame.py:251) when the store has one, else a dict
