@@ -287,7 +287,8 @@ int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, const float* 
  *   Qk[k] = sqrt(Qff[j] * Qkf[k]);  Cf = Cf_sum[j] * inv_nf;  Ck_avg[k] = Ck_sum[k] * inv_nk   (C / N of a Frame)
  *   valid_opt[k] = valid_match[k] & Cf > C_conf & Ck > C_conf & Qk > Q_conf;  valid_kf[k] = valid_match[k] & Qk > Q_conf
  *   T_rel = T_WCk^-1 * T_WCf (f32[8] each, unit quaternions as lietorch keeps them)
- *   workspace <- {i32 #valid_opt, i32 #valid_kf, i32 #distinct idx_f2k[k] with valid_match[k]} + a bitmap.
+ *   workspace (16-byte aligned) <- per-block counts of valid_opt / valid_kf + one byte flag per frame pixel that some
+ *   valid match points at (the verdict kernel counts them: the number of distinct idx_f2k[k] with valid_match[k]).
  * mslam_track_verdict: verdict6 <- {#valid_opt / n, iterations, chol_fail, #valid_kf / n, #distinct / n, done} with the
  *   solver status of mslam_track_pose (status_out) - the six scalars FrameTracker reads per frame.
  * mslam_track_fuse: T_WCf = T_WCk * T_rel;  X_new = ((C X_canon) + (Ckf (T_rel . Xkf))) / (C + Ckf);  C_new = C + Ckf. */

@@ -201,25 +201,24 @@ __global__ void track_init_kernel(TrackState* st) {
 // computed with the single IEEE operations the frontend's tensor expressions use (no contraction in this TU),
 // in the same order, so the fused form is bit-identical to the op-by-op form it replaces.
 // ---------------------------------------------------------------------------------------------
-struct PrepCounts {
-  int n_opt;      // valid_match & Cf > C_conf & Ck > C_conf & Qk > Q_conf
-  int n_kf;       // valid_match & Qk > Q_conf
-  int n_unique;   // distinct idx_f2k[k] among the pixels with valid_match
-  int pad;
-};
+// Workspace of mslam_track_prepare: [256 B reserved][int2 per block: #valid_opt, #valid_kf][n bytes: 1 = some valid
+// match points at this frame pixel].  No atomics: device-scope atomics with a return value serialise at the memory
+// side (the first form of this kernel spent 70-100 us on 196 608 atomicOr); flags are plain byte stores of the same
+// value, counted by the verdict kernel.
+__device__ __host__ inline size_t prep_partials_bytes(int n) { return (((size_t)((n + 255) / 256) * 8) + 255) & ~(size_t)255; }
 
 __global__ __launch_bounds__(256) void track_prep_kernel(
     const int64_t* __restrict__ idx, const uint8_t* __restrict__ vmatch, const float* __restrict__ Qff,
     const float* __restrict__ Qkf, const float* __restrict__ Cf_sum, float inv_nf, const float* __restrict__ Ck_sum,
     float inv_nk, float C_conf, float Q_conf, int n, const float* __restrict__ T_WCk, const float* __restrict__ T_WCf,
     float* __restrict__ Qk, float* __restrict__ Ck_avg, uint8_t* __restrict__ valid_opt, uint8_t* __restrict__ valid_kf,
-    float* __restrict__ T_rel, PrepCounts* __restrict__ counts, unsigned* __restrict__ bitmap) {
+    float* __restrict__ T_rel, int2* __restrict__ partial, uint8_t* __restrict__ hit) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k == 0) {   // T_CkCf = T_WCk^-1 * T_WCf, each factor a lietorch object (unit quaternion)
     const Sim3f Ti = sim3_unit(sim3_inv(sim3_load(T_WCk)));
     sim3_store(T_rel, sim3_unit(sim3_mul(Ti, sim3_load(T_WCf))));
   }
-  bool opt = false, kf = false, first = false;
+  bool opt = false, kf = false;
   if (k < n) {
     const long long j = idx[k];
     const bool vm = vmatch[k] != 0;
@@ -233,28 +232,47 @@ __global__ __launch_bounds__(256) void track_prep_kernel(
     Ck_avg[k] = ck;
     valid_opt[k] = opt ? 1 : 0;
     valid_kf[k] = kf ? 1 : 0;
-    if (vm) {
-      const unsigned bit = 1u << (j & 31);
-      first = (atomicOr(&bitmap[j >> 5], bit) & bit) == 0;
-    }
+    if (vm) hit[j] = 1;
   }
-  const int c_opt = __popcll(__ballot(opt)), c_kf = __popcll(__ballot(kf)), c_un = __popcll(__ballot(first));
-  if ((threadIdx.x & 63) == 0) {
-    if (c_opt) atomicAdd(&counts->n_opt, c_opt);
-    if (c_kf) atomicAdd(&counts->n_kf, c_kf);
-    if (c_un) atomicAdd(&counts->n_unique, c_un);
-  }
+  __shared__ int red[4][2];
+  const int c_opt = __popcll(__ballot(opt)), c_kf = __popcll(__ballot(kf));
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = c_opt; red[threadIdx.x >> 6][1] = c_kf; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partial[blockIdx.x] = make_int2(red[0][0] + red[1][0] + red[2][0] + red[3][0], red[0][1] + red[1][1] + red[2][1] + red[3][1]);
 }
 
 // {match_frac, iterations, chol_fail, kf_frac, unique_frac, done}: a mean of 0/1 values is count * (1 / n) in fp32
-__global__ void track_verdict_kernel(const PrepCounts* __restrict__ counts, const int* __restrict__ status, int n,
-                                     float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void track_verdict_kernel(const int2* __restrict__ partial, const uint8_t* __restrict__ hit,
+                                                             const int* __restrict__ status, int n, float* __restrict__ out) {
+  const int t = threadIdx.x;
+  int c[3] = {0, 0, 0};
+  const int nblk = (n + 255) / 256;
+  for (int b = t; b < nblk; b += 1024) { const int2 p = partial[b]; c[0] += p.x; c[1] += p.y; }
+  const int n16 = n >> 4;            // hit is 256-byte aligned: 16 flags per load, the tail byte by byte
+  for (int v = t; v < n16; v += 1024) {
+    const uint4 w = reinterpret_cast<const uint4*>(hit)[v];
+    c[2] += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);   // flags are 0 / 1 bytes
+  }
+  for (int v = (n16 << 4) + t; v < n; v += 1024) c[2] += hit[v];
+  __shared__ int red[16][3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    int s = c[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((t & 63) == 0) red[t >> 6][q] = s;
+  }
+  __syncthreads();
+  if (t != 0) return;
+  int tot[3] = {0, 0, 0};
+  for (int w = 0; w < 16; w++) { tot[0] += red[w][0]; tot[1] += red[w][1]; tot[2] += red[w][2]; }
   const float inv_n = 1.0f / (float)n;
-  out[0] = (float)counts->n_opt * inv_n;
+  out[0] = (float)tot[0] * inv_n;
   out[1] = (float)status[1];
   out[2] = (float)status[2];
-  out[3] = (float)counts->n_kf * inv_n;
-  out[4] = (float)counts->n_unique * inv_n;
+  out[3] = (float)tot[1] * inv_n;
+  out[4] = (float)tot[2] * inv_n;
   out[5] = (float)status[0];
 }
 
@@ -330,7 +348,7 @@ extern "C" int mslam_track_pose(int use_calib, float* T_rel, const float* Xf, co
 }
 
 extern "C" size_t mslam_track_prepare_workspace_bytes(int n_points) {
-  return 256 + 4 * (size_t)((n_points + 31) / 32);
+  return 256 + prep_partials_bytes(n_points) + (((size_t)n_points + 255) & ~(size_t)255);
 }
 
 extern "C" int mslam_track_prepare(const int64_t* idx_f2k, const uint8_t* valid_match, const float* Qff,
@@ -343,11 +361,13 @@ extern "C" int mslam_track_prepare(const int64_t* idx_f2k, const uint8_t* valid_
                     valid_kf && T_rel && workspace, "track_prepare: null pointer");
   MSLAM_REQUIRE(workspace_bytes >= mslam_track_prepare_workspace_bytes(n_points), "track_prepare: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int rc = check_hip(hipMemsetAsync(workspace, 0, mslam_track_prepare_workspace_bytes(n_points), s), "track_prepare: memset");
+  MSLAM_REQUIRE(((uintptr_t)workspace & 15) == 0, "track_prepare: workspace must be 16-byte aligned");
+  uint8_t* hit = (uint8_t*)workspace + 256 + prep_partials_bytes(n_points);
+  int rc = check_hip(hipMemsetAsync(hit, 0, (size_t)n_points, s), "track_prepare: memset");
   if (rc) return rc;
   hipLaunchKernelGGL(track_prep_kernel, dim3((n_points + 255) / 256), dim3(256), 0, s, idx_f2k, valid_match, Qff, Qkf,
                      Cf_sum, inv_nf, Ck_sum, inv_nk, C_conf, Q_conf, n_points, T_WCk, T_WCf, Qk, Ck_avg, valid_opt,
-                     valid_kf, T_rel, (PrepCounts*)workspace, (unsigned*)((char*)workspace + 256));
+                     valid_kf, T_rel, (int2*)((char*)workspace + 256), hit);
   MSLAM_LAUNCH_CHECK("track_prepare");
   return MSLAM_OK;
 }
@@ -355,8 +375,9 @@ extern "C" int mslam_track_prepare(const int64_t* idx_f2k, const uint8_t* valid_
 extern "C" int mslam_track_verdict(const void* prepare_workspace, const void* status, int n_points, float* verdict6,
                                    void* stream) {
   MSLAM_REQUIRE(prepare_workspace && status && verdict6 && n_points > 0, "track_verdict: bad arguments");
-  hipLaunchKernelGGL(track_verdict_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const PrepCounts*)prepare_workspace,
-                     (const int*)status, n_points, verdict6);
+  const char* ws = (const char*)prepare_workspace;
+  hipLaunchKernelGGL(track_verdict_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int2*)(ws + 256),
+                     (const uint8_t*)(ws + 256 + prep_partials_bytes(n_points)), (const int*)status, n_points, verdict6);
   MSLAM_LAUNCH_CHECK("track_verdict");
   return MSLAM_OK;
 }
