@@ -230,6 +230,10 @@ class FactorGraph:
                 c["X"][r].copy_(kf.X_canon)
                 c["C"][r].copy_(kf.get_average_conf())
                 c["keys"][r] = key
+                if kf.X_canon.is_cuda:     # the tracking side may replace (and so free) this keyframe's tensors, which
+                    cur = torch.cuda.current_stream(dev)   # were allocated on ITS stream, while these copies are queued
+                    kf.X_canon.record_stream(cur)
+                    kf.C.record_stream(cur)
         T_WCs = Sim3(torch.stack([kf.T_WC.data for kf in kfs]))
         return c["X"][:P], T_WCs, c["C"][:P]
 

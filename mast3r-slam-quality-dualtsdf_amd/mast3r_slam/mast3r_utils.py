@@ -93,6 +93,11 @@ def mast3r_decode_symmetric_batch(model, feat_i, pos_i, feat_j, pos_j, shape_i, 
         return downsample(pick("pts3d"), pick("conf"), pick("desc"), pick("desc_conf"))  # X: (4, B, H, W, 3)
     keep = [r for r in range(2 * B) if r not in cached]
     out = []
+    if f1.is_cuda:      # the cached rows were produced (and allocated) on the tracking stream; the caller drops them right
+        cur = torch.cuda.current_stream(f1.device)   # after this call, while the copies below are still queued on this stream
+        for res in cached.values():
+            for t in res:
+                t.record_stream(cur)
     if keep:
         sel = torch.tensor(keep, device=f1.device)
         ra, rb = model.decode_pair(f1[sel].contiguous(), f2[sel].contiguous(), H, W)

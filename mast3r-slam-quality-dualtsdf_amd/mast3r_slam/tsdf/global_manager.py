@@ -60,6 +60,10 @@ class TSDFGlobalIntegrator:
         if idx >= len(self.keyframes):
             return None
         frame = self.keyframes[idx]
+        if frame.X_canon.is_cuda:      # allocated on the tracking stream, which may replace the keyframe while the clones
+            cur = torch.cuda.current_stream(frame.X_canon.device)   # below are still queued on this one
+            for t in (frame.X_canon, frame.C, frame.T_WC.data):
+                t.record_stream(cur)
         return (frame.X_canon.detach().clone(), frame.C.detach().clone(), frame.T_WC.data.clone())
 
     def _integrate_single(self, idx):
