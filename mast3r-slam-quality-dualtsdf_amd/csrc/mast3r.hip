@@ -462,7 +462,12 @@ struct Mast3rModel {
   bool two_streams = true;
   int fork_max_rows = 1 << 30;           // MSLAM_FORK_MAX_M: calls with more token rows per side stay on one queue
   bool dec_grouped = true;               // both decoder sides per launch (MSLAM_DEC_GROUPED=0: one queue per side)
-  int group_max_rows = 1024;             // ... up to this many token rows per side (MSLAM_GROUP_MAX_M), two queues above (measured)
+  // ... up to this many token rows per side (MSLAM_GROUP_MAX_M), two queues above.  Round 1 / 2 measured the switch-over
+  // at 1 024 rows with the stage ALONE on the chip (two queues hide each other's launch bubbles: 7.3 vs 7.8 ms for a decode
+  // of four frames); inside the loop, where the other streams keep the chip busy anyway, what counts is the work a launch
+  // costs, and one launch over both sides does the same FLOP in ~20 % less GEMM time (6144x768x768 16 us against
+  // 2 x 10 us, ...): always grouped measures +4-5 % frames/s end to end (profiles/r03_decoder_grouping_ab.log)
+  int group_max_rows = 1 << 30;
   mutable std::mutex fork_mu;
   mutable std::map<hipStream_t, Fork*> forks;
   Fork* fork_for(hipStream_t caller, int& rc) const {
