@@ -459,7 +459,11 @@ struct Mast3rModel {
   };
   unsigned* pf_sink = nullptr;           // 4 scratch bytes behind the RoPE tables (gemm.h: pf_sink)
   bool prefetch = true;                  // MSLAM_PREFETCH=0: no weight prefetch blocks
-  bool two_streams = true;
+  // The two heads (and, when the decoder is not grouped, its two sides) of a decode call on two queues.  Pays with the
+  // call ALONE on the chip (round 1: 7.3 vs 9.5 ms for four frames); inside the loop the other streams fill the chip and
+  // one queue measures +4 % frames/s at 60-120 keyframes, neutral at 64 (profiles/r03_decoder_grouping_ab.log): off by
+  // default since round 3 (MSLAM_TWO_STREAMS=1 turns it on; results do not depend on it)
+  bool two_streams = false;
   int fork_max_rows = 1 << 30;           // MSLAM_FORK_MAX_M: calls with more token rows per side stay on one queue
   bool dec_grouped = true;               // both decoder sides per launch (MSLAM_DEC_GROUPED=0: one queue per side)
   // ... up to this many token rows per side (MSLAM_GROUP_MAX_M), two queues above.  Round 1 / 2 measured the switch-over
@@ -1088,7 +1092,8 @@ extern "C" int mslam_mast3r_create(void** handle_out, const int* cfg9, void* con
   if (!rc) rc = check_hip(hipMemcpyAsync(m->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream), "rope copy");
   if (!rc) rc = check_hip(hipMemcpyAsync(m->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, (hipStream_t)stream), "rope copy");
   if (!rc) rc = check_hip(hipStreamSynchronize((hipStream_t)stream), "rope sync");
-  m->two_streams = getenv("MSLAM_SINGLE_STREAM") == nullptr;
+  if (const char* e = getenv("MSLAM_TWO_STREAMS")) m->two_streams = atoi(e) != 0;
+  if (getenv("MSLAM_SINGLE_STREAM")) m->two_streams = false;
   if (const char* e = getenv("MSLAM_FORK_MAX_M")) m->fork_max_rows = atoi(e);
   if (const char* e = getenv("MSLAM_PREFETCH")) m->prefetch = atoi(e) != 0;
   if (const char* e = getenv("MSLAM_DEC_GROUPED")) m->dec_grouped = atoi(e) != 0;
