@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--graphs", action="store_true", help="replay the network as captured HIP graphs (default: eager)")
     ap.add_argument("--no-backend-thread", action="store_true",
                     help="run the keyframe backend inline in the tracking loop (the reference's single_thread mode)")
-    ap.add_argument("--frame-group", type=int, default=4,
+    ap.add_argument("--frame-group", type=int, default=6,
                     help="frames whose network stages run in one batch call (SlamSystem frame groups)")
     ap.add_argument("--backend-stages", type=int, default=3,
                     help="threaded backend: stages of the keyframe task on threads / streams of their own - graph stage "
@@ -97,8 +97,9 @@ def parse():
                          "refinement; 2 = together with the solve); 1 = one thread does the whole keyframe task")
     ap.add_argument("--solve-priority", type=int, default=0,
                     help="HIP stream priority of the backend's solve stage (-1 = high): a chain of short kernels and host reads")
-    ap.add_argument("--encoder-group", type=int, default=0,
-                    help="frames per look-ahead encoder call (0 = the frame group)")
+    ap.add_argument("--encoder-group", type=int, default=12,
+                    help="frames per look-ahead encoder call (0 = the frame group; every frame is encoded exactly once, so "
+                         "a larger batch costs nothing but look-ahead)")
     ap.add_argument("--decode-ahead", type=int, default=0,
                     help="SlamSystem decode_ahead: issue the next group's pair decode on its own stream when at most this "
                          "many decoded frames are left (0: on the tracking stream when none is left)")
@@ -654,14 +655,18 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
         dom_gflop = 2e-9 * M * N * K
         dom_tflops = dom_gflop * 1e3 / avg_us.value if nsamp.value else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_dominant_kernel.json")
-        if os.path.exists(tpath):   # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the same launch, separate passes (tools/pmc_sum.py)
+        import glob
+
+        # PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the same launch, separate passes (tools/pmc_probe.sh): the committed
+        # record of THIS shape, newest round first
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dominant_kernel*.json")), reverse=True):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("shape") == [M, N, K]:
+                if tj.get("shape") == [M, N, K] and tj.get("hbm_bytes_per_launch"):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    break
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "SLAM frames/sec (infer+match+TSDF+GN) @512x384", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

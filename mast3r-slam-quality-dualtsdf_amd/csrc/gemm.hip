@@ -31,6 +31,11 @@ static std::unordered_map<uint64_t, int> g_tile_override = {
     // round 2 (tools/gemm_cfg_ab.py, interleaved A/B in one process, profiles/r02_gemm_cfg_ab.log)
     {tile_key(3072, 4096, 1024), 2192},   // encoder fc1 at a frame group of 4: 16 x 16 tiles of 192x256 = one per CU (256x256: 192 tiles)
     {tile_key(6144, 4096, 1024), 1282},   // the same at a group of 8: 384 tiles of 256x256 are one and a half rounds
+    // round 3, encoder batches of 12 / 6 frames (bench default; tools/gemm_cfg_ab.py, gpurun_out -> profiles/r03_gemm_cfg_ab_group12.log)
+    {tile_key(9216, 4096, 1024), 1282},   // fc1 + GELU: 96 us against 110 us for 576 tiles of 256x256 (2.25 rounds; the epilogue of a
+                                          // 128x128 tile drains beside its neighbours' K loops)
+    {tile_key(9216, 1024, 4096), 8256},   // fc2: phase-interleaved kernel, 78 us against 86 us
+    {tile_key(4608, 4096, 1024), 1282},   // fc1 + GELU at 6 frames: 54 us against 70 us
 };
 
 int gemm_tile_override(int M, int N, int K, int cfg, bool conv) {
