@@ -10,7 +10,8 @@ loop + run_backend, one process) over frames of the procedural room (SURVEY §8d
 A "step" is one frame through that loop:
   tracking   encode(frame) -> asymmetric decode + heads vs the last keyframe -> iterative-projection match + fp16
              descriptor refinement -> frame-to-keyframe Sim3 Gauss-Newton -> keyframe decision (match fractions)
-  per new keyframe (backend, own host thread + stream as the reference's backend process):
+  per new keyframe (backend: three stages - graph | solve | fusion - on host threads + streams of their own, so that
+             consecutive keyframe tasks overlap; the reference's backend is a process of its own):
              retrieval of <= 3 earlier keyframes + the consecutive one -> symmetric decode + heads of those pairs (both
              directions, one batch) -> matching of both directions -> global Sim3 GN over the WHOLE keyframe graph ->
              global TSDF: fuse the keyframe's 40 000 points, re-fuse / pose-refine queued keyframes -> local TSDF block
