@@ -604,7 +604,9 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
     st0["verdict_wait_s"] = ses.system.tracker.verdict_wait_s
     st0["backend_phase_s"] = dict(st0.get("backend_phase_s", {}))
     rows0 = (ses.model.enc_rows, ses.model.dec_rows)
-    M, N, K = dominant_shape(max(B, ses.system.encoder_group))   # the look-ahead encoder's batch
+    # the look-ahead encoder's batch: calls do not cross the end of a run() segment, so a timed region shorter than the
+    # batch sees ONE call of `steps` frames
+    M, N, K = dominant_shape(min(max(B, ses.system.encoder_group), max(1, args.steps)))
     mslam_hip.check(L.mslam_gemm_profile_begin(M, N, K, 8192), "gemm_profile_begin")
     prof = None
     if os.environ.get("BENCH_CPROFILE"):   # debug: where the frontend thread's host time goes
