@@ -700,7 +700,8 @@ def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
                                  "refine_blocks": st1.get("refine_blocks", 0) - st0.get("refine_blocks", 0),
                                  "relocalised": st1["relocalised"] - st0["relocalised"],
                                  "replayed_frames": st1.get("replayed_frames", 0) - st0.get("replayed_frames", 0),
-                                 "frontend_host_ms_per_step": 1e3 * t_enqueued / args.steps,
+                                 "frontend_host_ms_per_step": 1e3 * t_enqueued / args.steps,      # whole loop iteration on the host
+                                 "frontend_enqueue_ms_per_step": 1e3 * (t_enqueued - t_wait) / args.steps,
                                  "frontend_wait_for_device_ms_per_step": 1e3 * t_wait / args.steps},
                        "parallelism": f"{world} independent session(s), one per GPU (replicas; {ranks_seen} rank(s) reported by the collective library)"},
             "roofline": {"bound": "mfma", "achieved": dom_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
