@@ -18,11 +18,12 @@ class RoomModel:
 
     def __init__(self, device, noise=0.001):
         self.device, self.noise = device, noise
-        self.enc_calls, self.dec_calls, self.dec_rows = 0, 0, 0
+        self.enc_calls, self.enc_rows, self.dec_calls, self.dec_rows = 0, 0, 0, 0
 
     def _encode_image(self, img, true_shape=None):
         self.enc_calls += 1
         B = img.shape[0]
+        self.enc_rows += B
         n = (H // 16) * (W // 16)
         k = torch.round(img.reshape(B, -1)[:, 0] * 1000.0)
         feat = k.reshape(B, 1, 1).expand(B, n, 1024).contiguous().float()
@@ -51,7 +52,8 @@ def _frames(ks, device):
                   torch.zeros(H, W, 3)) for i, k in enumerate(ks)]
 
 
-def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=False, pipeline=False, depth=2, reuse=True):
+def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=False, pipeline=False, depth=2, reuse=True,
+         encoder_group=None):
     from mast3r_slam.config import config
     from mast3r_slam.slam_system import SlamSystem
 
@@ -64,7 +66,7 @@ def _run(device, ks, frame_group, tsdf=False, backend="inline", shared_store=Fal
 
         store = SharedKeyframes(None, H, W, buffer=16, device=device)
     system = SlamSystem(model, device, frame_group=frame_group, tsdf_global_cfg=tcfg, backend=backend, keyframes=store,
-                        pipeline=pipeline, pipeline_depth=depth)
+                        pipeline=pipeline, pipeline_depth=depth, encoder_group=encoder_group)
     system.factor_graph.reuse_tracking_decode = reuse
     frames = _frames(ks, device)
     res = system.run(frames)
@@ -138,6 +140,20 @@ def test_frame_groups_are_bit_identical(device, group, eager_keyframes):
     n_kf = len(sg.keyframes)
     assert sg.stats["void_rows"] <= (group - 1) * n_kf
     assert sg.stats["decoded_rows"] == len(ks) - 1 + sg.stats["void_rows"]
+
+
+def test_larger_encoder_batches_change_nothing(device, eager_keyframes):
+    """The look-ahead encoder may run on more frames per call than the decode group (bench default 12 / 6): every frame is
+    encoded exactly once, in fewer calls, and nothing downstream changes by a bit (threaded, staged backend)."""
+    ks = list(range(0, 66, 3))
+    s1, m1, f1, r1 = _run(device, ks, 3, tsdf=True)
+    sg, mg, fg, rg = _run(device, ks, 3, tsdf=True, encoder_group=7)
+    assert [r["new_kf"] for r in r1] == [r["new_kf"] for r in rg]
+    for a, b in zip(f1, fg):
+        assert torch.equal(a.T_WC.data, b.T_WC.data) and torch.equal(a.X_canon, b.X_canon) and torch.equal(a.C, b.C)
+    for i in range(len(s1.keyframes)):
+        assert torch.equal(s1.keyframes[i].T_WC.data, sg.keyframes[i].T_WC.data)
+    assert mg.enc_calls < m1.enc_calls and mg.enc_rows == m1.enc_rows == len(ks)
 
 
 def test_shared_keyframe_buffers_give_the_same_trajectory(device, eager_keyframes):

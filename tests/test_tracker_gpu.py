@@ -125,3 +125,41 @@ def test_fused_glue_equals_tensor_expressions(device, hw):
     assert torch.equal(T_out, (T_WCk * T_CkCf).data.reshape(1, 8))
     assert torch.equal(X_new, ((Ck_sum * Xc) + (Ckf * Xkk)) / (Ck_sum + Ckf))
     assert torch.equal(C_new, Ck_sum + Ckf)
+
+
+def test_fused_glue_edge_cases(device):
+    """mslam_track_prepare / _verdict at a point count that is no multiple of a wave, a block or 16 bytes, with no valid match
+    at all and with every match pointing at one pixel."""
+    import mslam_hip as m
+    from lietorch_hip import Sim3
+
+    L = m.lib()
+    for n, mode in ((1003, "none"), (1003, "one"), (257, "all"), (5, "all")):
+        g = torch.Generator().manual_seed(n)
+        idx = torch.randint(0, n, (n,), generator=g).to(device)
+        vm = torch.ones(n, 1, dtype=torch.bool, device=device)
+        if mode == "none":
+            vm.zero_()
+        if mode == "one":
+            idx.fill_(n - 1)
+        Qff = Qkf = torch.full((n, 1), 4.0, device=device)
+        Cs = torch.full((n, 1), 2.0, device=device)
+        T = Sim3.Identity(1, device=device)
+        ws = torch.empty(L.mslam_track_prepare_workspace_bytes(n), dtype=torch.uint8, device=device)
+        ws.fill_(255)                                   # the call must not rely on a zeroed workspace
+        Qk, Ck = torch.empty(n, 1, device=device), torch.empty(n, 1, device=device)
+        vo, vk = torch.empty(n, 1, dtype=torch.bool, device=device), torch.empty(n, 1, dtype=torch.bool, device=device)
+        T_rel = torch.empty(8, device=device)
+        m.check(L.mslam_track_prepare(m.ptr(idx), m.ptr(vm), m.ptr(Qff), m.ptr(Qkf), m.ptr(Cs), 1.0, m.ptr(Cs), 1.0, 0.0, 1.5, n,
+                                      m.ptr(T.data), m.ptr(T.data), m.ptr(Qk), m.ptr(Ck), m.ptr(vo), m.ptr(vk), m.ptr(T_rel),
+                                      m.ptr(ws), ws.numel(), m.stream_ptr()), "track_prepare")
+        status = torch.tensor([0, 2, 1, 0, 0, 0, 0, 0], dtype=torch.int32, device=device)
+        v6 = torch.empty(6, device=device)
+        m.check(L.mslam_track_verdict(m.ptr(ws), m.ptr(status), n, m.ptr(v6), m.stream_ptr()), "track_verdict")
+        hits = torch.zeros(n, dtype=torch.int32, device=device)
+        hits.index_add_(0, idx, vm[:, 0].to(torch.int32))
+        want = torch.stack((vm.float().mean(), status[1].float(), status[2].float(), vm.float().mean(),
+                            (hits > 0).float().mean(), status[0].float()))
+        assert torch.equal(v6, want), (n, mode, v6, want)
+        assert torch.equal(vo, vm) and torch.equal(vk, vm) and torch.equal(Qk, torch.full_like(Qk, 4.0))
+        assert torch.equal(T_rel, T.data.reshape(8))
