@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the hand-written network kernels (not part of the test suite):
-python tools/bench_kernels.py  -> one line per shape with us/launch and TFLOP/s."""
+python tools/bench_kernels.py [shipped]  -> one line per shape with us/launch and TFLOP/s (shipped: the shapes of the
+round-3 loop: encoder batches of 12, decode groups of 6)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mast3r-slam-quality-dualtsdf_amd")]
@@ -67,6 +68,32 @@ def ln(rows, D):
     us = timeit(lambda: L.mslam_layernorm_f32(m.ptr(x), m.ptr(w), m.ptr(b), m.ptr(ob), 0, rows, D, 1e-6, m.stream_ptr()))
     print(f"layernorm {rows}x{D}: {us:8.1f} us  {rows * D * 6 / us * 1e-3:7.1f} GB/s")
 
+
+if __name__ == "__main__" and os.path.basename(sys.argv[0]) == "bench_kernels.py" and "shipped" in sys.argv[1:]:
+    # the shapes of the shipped loop (round 3): encoder on 12 frames (9 216 rows), decoder + heads on 6 pairs (4 608 rows per
+    # side; both sides in one grouped launch inside the network - here one side alone), backend batch of 8 rows
+    print("# encoder, 12 frames")
+    for shp in [(9216, 3072, 1024), (9216, 1024, 1024), (9216, 1024, 4096)]:
+        gemm(*shp)
+    gemm(9216, 4096, 1024, act=1)
+    attn(12, 16, 768)
+    ln(9216, 1024)
+    print("# decoder, 6 pairs (one side)")
+    for shp in [(4608, 2304, 768), (4608, 768, 768), (4608, 1536, 768), (4608, 768, 3072)]:
+        gemm(*shp)
+    gemm(4608, 3072, 768, act=1)
+    attn(12, 12, 768)
+    ln(4608, 768)
+    print("# heads, 6 images")
+    conv(6, 384, 512, 128, 128)
+    conv(6, 192, 256, 256, 128)
+    conv(6, 96, 128, 256, 256)
+    conv(6, 48, 64, 256, 256)
+    conv(6, 24, 32, 768, 256)
+    conv(6, 24, 32, 1024, 96, ks=1)
+    gemm(4608, 7168, 1792)
+    gemm(4608, 6400, 7168)
+    sys.exit(0)
 
 if __name__ == "__main__" and os.path.basename(sys.argv[0]) == "bench_kernels.py":
     for shp in [(768, 1024, 1024), (768, 3072, 1024), (768, 4096, 1024), (768, 1024, 4096), (768, 768, 768),
