@@ -156,6 +156,26 @@ def test_larger_encoder_batches_change_nothing(device, eager_keyframes):
     assert mg.enc_calls < m1.enc_calls and mg.enc_rows == m1.enc_rows == len(ks)
 
 
+@pytest.mark.parametrize("mode", ["indep_conf", "recent", "first", "weighted_spherical"])
+def test_other_filtering_modes(device, mode, eager_keyframes, monkeypatch):
+    """The fused fusion launch covers the default 'weighted_pointmap' (frame.py:72-75); every other filtering mode of
+    Frame.update_pointmap goes through the op-by-op path of FrameTracker._apply: same loop, frame groups still bit-identical,
+    trajectory still recovered."""
+    from mast3r_slam.config import config
+
+    monkeypatch.setitem(config["tracking"], "filtering_mode", mode)
+    ks = list(range(0, 45, 3))
+    s1, m1, f1, r1 = _run(device, ks, 1)
+    sg, mg, fg, rg = _run(device, ks, 3)
+    assert len(s1.keyframes) >= 2 and [r["new_kf"] for r in r1] == [r["new_kf"] for r in rg]
+    for a, b in zip(f1, fg):
+        assert torch.equal(a.T_WC.data, b.T_WC.data) and torch.isfinite(a.T_WC.data).all()
+    T0 = synthetic.camera_pose(ks[0])
+    for i, f in enumerate(f1):
+        err = np.linalg.norm(f.T_WC.data.reshape(-1)[:3].cpu().numpy() - _gauge(T0, synthetic.camera_pose(ks[i])))
+        assert err < 0.08, (mode, i, err)
+
+
 def test_shared_keyframe_buffers_give_the_same_trajectory(device, eager_keyframes):
     """SlamSystem on the SharedKeyframes slot buffers (the reference's data layout contract) and on the
     plain list store: identical poses, keyframes and graph."""
