@@ -33,3 +33,17 @@ print(f"at least one kernel resident: {100 * busy / win:.1f} % of the window; id
 print("name,calls,total_us,percent,avg_us,min_us")
 for r in rows[:top]:
     print('"%s",%d,%.1f,%.2f,%.2f,%.2f' % (r[0][:120], r[1], r[2], 100 * r[2] / tot, r[3], r[4]))
+
+# Optional 4th argument: a substring of a kernel name -> the same window split by launch grid (one line per grid size), so
+# that ONE shape of an instantiation shared by several shapes can be read off (e.g. the dominant GEMM: its grid is
+# ceil(M / BM) * ceil(N / BN) tiles + the prefetch blocks).
+if len(sys.argv) > 4:
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)").fetchall()]
+    gcol = next((c for c in ("grid_x", "grid_size_x", "grid_size", "grid") if c in cols), None)
+    wcol = next((c for c in ("workgroup_x", "workgroup_size_x", "workgroup_size") if c in cols), None)
+    print(f"# launches of kernels matching '{sys.argv[4]}' by grid ({gcol} / {wcol}); columns available: {cols}")
+    if gcol:
+        sel = f"{gcol}" + (f", {wcol}" if wcol else "")
+        for r in db.execute(f"select name, {sel}, count(*), avg(end-start)/1e3, min(end-start)/1e3 from kernels where start >= ? and name like ? "
+                            f"group by name, {sel} order by 4 desc", (t0, f"%{sys.argv[4]}%")).fetchall():
+            print(",".join(str(x)[:100] if i == 0 else (f"{x:.2f}" if isinstance(x, float) else str(x)) for i, x in enumerate(r)))
