@@ -561,7 +561,7 @@ def main():
     if world > 1 and mode in ("auto", "shard-backend"):
         if out is not None:
             torch.cuda.empty_cache()
-        sb = measure_sharded_backend(args, rank, world, dev, ranks_seen)
+        sb = guarded_sharded_backend(args, rank, world, dev, ranks_seen, out)
         if rank == 0:
             if out is None:   # --mode shard-backend: the sharded session is the line's value
                 out = {"metric": "SLAM frames/sec (infer+match+TSDF+GN) @512x384", "value": sb["value"], "unit": "frames/s",
@@ -578,6 +578,40 @@ def main():
 
         dist.barrier()
         dist.destroy_process_group()
+
+
+def guarded_sharded_backend(args, rank, world, dev, ranks_seen, out):
+    """measure_sharded_backend behind a watchdog.  The replica figure (`out`, the line's `value`) is already measured when
+    the sharded session starts; a session that raises on one rank leaves the others inside a collective, and one that hangs
+    (this path has only ever run on one card) would take the whole line with it.  Every rank therefore arms the same timer
+    (BENCH_SHARD_TIMEOUT seconds, default 300) at the same barrier: if the session has not finished by then - or raises -
+    rank 0 prints the line with `sharded_backend: {"error": ...}` and every rank leaves with exit code 0 (3 when the
+    sharded session WAS the requested measurement, --mode shard-backend)."""
+    import threading
+    import traceback
+
+    timeout = float(os.environ.get("BENCH_SHARD_TIMEOUT", "300"))
+
+    def bail(reason):
+        if rank == 0:
+            print(f"[bench] sharded session abandoned: {reason}", file=sys.stderr, flush=True)
+            if out is not None:
+                out["sharded_backend"] = {"error": reason}
+                print(json.dumps(out), flush=True)
+        os._exit(0 if out is not None else 3)
+
+    barrier(world)
+    timer = threading.Timer(timeout, bail, args=(f"did not finish within {timeout:.0f} s",))
+    timer.daemon = True
+    timer.start()
+    try:
+        sb = measure_sharded_backend(args, rank, world, dev, ranks_seen)
+    except Exception as e:      # this rank leaves; the others run into their own timers
+        traceback.print_exc()
+        timer.cancel()
+        bail(f"rank {rank}: {type(e).__name__}: {e}")
+    timer.cancel()
+    return sb
 
 
 def measure_replicas(args, rank, world, dev, L, mslam_hip, ranks_seen):
