@@ -561,7 +561,7 @@ def main():
     if world > 1 and mode in ("auto", "shard-backend"):
         if out is not None:
             torch.cuda.empty_cache()
-        sb = guarded_sharded_backend(args, rank, world, dev, ranks_seen, out)
+        sb = guarded_sharded_backend(args, rank, world, dev, ranks_seen, out, mode == "auto")
         if rank == 0:
             if out is None:   # --mode shard-backend: the sharded session is the line's value
                 out = {"metric": "SLAM frames/sec (infer+match+TSDF+GN) @512x384", "value": sb["value"], "unit": "frames/s",
@@ -580,7 +580,7 @@ def main():
         dist.destroy_process_group()
 
 
-def guarded_sharded_backend(args, rank, world, dev, ranks_seen, out):
+def guarded_sharded_backend(args, rank, world, dev, ranks_seen, out, replicas_done):
     """measure_sharded_backend behind a watchdog.  The replica figure (`out`, the line's `value`) is already measured when
     the sharded session starts; a session that raises on one rank leaves the others inside a collective, and one that hangs
     (this path has only ever run on one card) would take the whole line with it.  Every rank therefore arms the same timer
@@ -598,7 +598,7 @@ def guarded_sharded_backend(args, rank, world, dev, ranks_seen, out):
             if out is not None:
                 out["sharded_backend"] = {"error": reason}
                 print(json.dumps(out), flush=True)
-        os._exit(0 if out is not None else 3)
+        os._exit(0 if replicas_done else 3)     # (`out` exists on rank 0 only)
 
     barrier(world)
     timer = threading.Timer(timeout, bail, args=(f"did not finish within {timeout:.0f} s",))
