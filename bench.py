@@ -34,6 +34,8 @@ it already runs under torch.distributed.run.  Two things are measured at N > 1, 
     N ranks (mast3r_slam/shard.py) - rank 0 tracks and drives, keyframe-pair inference + matching are split over the
     ranks and all-gathered, the global GN accumulates each rank's edges and sums the normal-equation blocks with ONE
     all-reduce per iteration (RCCL over xGMI), the global TSDF's voxels live on their owner ranks.  `--mode` picks one.
+    The replicas are measured first; the sharded session runs behind a watchdog (BENCH_SHARD_TIMEOUT, default 300 s) so
+    that a failure there still leaves the line with `value` and `sharded_backend: {"error": ...}`.
 Prints ONE JSON line on rank 0.
 """
 import argparse
